@@ -1,0 +1,222 @@
+/*
+ * fosphor_portable_math.h -- pinned, bit-reproducible math primitives
+ *
+ * The reference kernels call OpenCL built-ins whose results are implementation
+ * defined: native_sin / native_cos (fft.cl:66-67), hypot / log10 / round
+ * (display.cl:136,161).  "The reference result" is therefore only defined up
+ * to the choice of an OpenCL runtime's libm.  This header pins that choice:
+ * every function below is built from IEEE-754 double {+,-,*,/,sqrt} and
+ * integer bit manipulation only, evaluated in a fixed order, so it returns the
+ * same bits under gcc, clang and hipcc host compilation, on any machine,
+ * provided the translation unit is compiled with -ffp-contract=off.
+ *
+ * Users:
+ *   - oracle/ref_shim.cpp binds the reference kernels' built-ins to these
+ *     (the "portable" binding), which makes the oracle bit-exact;
+ *   - oracle/fosphor_oracle.c (CPU restatement) calls them directly;
+ *   - the product host code (gr-fosphor_amd/csrc) uses them to generate the
+ *     twiddle table and the exact histogram-bin thresholds uploaded to the GPU.
+ *     The GPU never evaluates log10/hypot for binning: it compares against
+ *     thresholds derived from these functions ("exact binning").
+ *
+ * All functions are `static inline`; C99 and C++11 compatible.
+ */
+#ifndef FOSPHOR_PORTABLE_MATH_H
+#define FOSPHOR_PORTABLE_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__clang__)
+#pragma STDC FP_CONTRACT OFF
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+static inline uint64_t fpm_d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double   fpm_u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+static inline uint32_t fpm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float    fpm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---- |X|^2 in double: exact products, one rounding on the sum ------------ */
+static inline double fpm_sqmag(float re, float im)
+{
+	double x = (double)re, y = (double)im;
+	return x * x + y * y;	/* both products are exact in binary64 */
+}
+
+/* ---- hypot: stands in for OpenCL hypot(float,float), display.cl:136 ------ */
+/* h = (float)sqrt(re^2 + im^2) with the sum formed in double.  Matches glibc
+ * 2.35 hypotf bit for bit on 2e8 random pairs (SURVEY H1 probe). */
+static inline float fpm_hypot_from_sqmag(double s)
+{
+	return (float)sqrt(s);	/* IEEE sqrt is correctly rounded */
+}
+
+static inline float fpm_hypotf(float re, float im)
+{
+	if (isinf(re) || isinf(im))
+		return INFINITY;	/* C99 hypot(inf, nan) == inf */
+	return fpm_hypot_from_sqmag(fpm_sqmag(re, im));
+}
+
+/* ---- log10: stands in for OpenCL log10(float), display.cl:136 ------------ */
+/* ln(m) = 2 atanh((m-1)/(m+1)) on m in [1/sqrt2, sqrt2), 11 odd terms in
+ * double (truncation < 5e-17 relative), result rounded once to float. */
+static inline float fpm_log10f(float h)
+{
+	static const double LN2      = 6.93147180559945286227e-01;
+	static const double INV_LN10 = 4.34294481903251816668e-01;
+	static const double SQRT2    = 1.41421356237309514547e+00;
+
+	double d, m, z, z2, p, lnm;
+	uint64_t u;
+	int e;
+
+	if (h != h)
+		return h;			/* NaN */
+	if (h < 0.0f)
+		return NAN;
+	if (h == 0.0f)
+		return -INFINITY;
+	if (isinf(h))
+		return INFINITY;
+
+	d = (double)h;				/* float denormals become normal doubles */
+	u = fpm_d2u(d);
+	e = (int)((u >> 52) & 0x7ff) - 1023;
+	m = fpm_u2d((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);	/* [1,2) */
+	if (m > SQRT2) {
+		m = m * 0.5;
+		e = e + 1;
+	}
+
+	z  = (m - 1.0) / (m + 1.0);
+	z2 = z * z;
+	p  = 2.0 / 21.0;
+	p  = p * z2 + 2.0 / 19.0;
+	p  = p * z2 + 2.0 / 17.0;
+	p  = p * z2 + 2.0 / 15.0;
+	p  = p * z2 + 2.0 / 13.0;
+	p  = p * z2 + 2.0 / 11.0;
+	p  = p * z2 + 2.0 / 9.0;
+	p  = p * z2 + 2.0 / 7.0;
+	p  = p * z2 + 2.0 / 5.0;
+	p  = p * z2 + 2.0 / 3.0;
+	p  = p * z2 + 2.0;
+	lnm = p * z;
+
+	return (float)(((double)e * LN2 + lnm) * INV_LN10);
+}
+
+/* ---- round: OpenCL round() = half away from zero, display.cl:161 --------- */
+static inline float fpm_roundf(float v)
+{
+	float a, t, f;
+	a = fabsf(v);
+	if (!(a < 8388608.0f))
+		return v;			/* NaN, inf, or already integral */
+	t = (float)(int32_t)a;			/* truncation, exact */
+	f = a - t;				/* exact: t <= a < t+1 < 2^23 */
+	if (f >= 0.5f)
+		t = t + 1.0f;
+	return copysignf(t, v);
+}
+
+/* ---- value -> histogram bin, display.cl:161-168 with CLAMP --------------- */
+/* Non-finite scaled values map to bin 0: (int)inf / (int)NaN is undefined in
+ * OpenCL C; the x86 build of the reference yields INT_MIN -> clamped to 0,
+ * and -inf (log10 of 0) also clamps to 0.  Pinned here explicitly. */
+static inline int fpm_bin_from_pwr(float pwr, float histo_scale, float histo_ofs, int n_bins)
+{
+	float v = histo_scale * (pwr + histo_ofs);
+	float r;
+	if (v != v || isinf(v))
+		return 0;
+	r = fpm_roundf(v);
+	if (r < 0.0f)
+		return 0;
+	if (r > (float)(n_bins - 1))
+		return n_bins - 1;
+	return (int)r;
+}
+
+/* Bin as a function of the double squared magnitude -- the form the GPU
+ * thresholds are derived from.  Monotone non-decreasing in s for finite
+ * hypot; s large enough that hypot overflows float gives bin 0 (see above). */
+static inline int fpm_bin_from_sqmag(double s, float histo_scale, float histo_ofs, int n_bins)
+{
+	float h;
+	if (s != s)
+		return 0;
+	h = isinf(s) ? INFINITY : fpm_hypot_from_sqmag(s);
+	return fpm_bin_from_pwr(fpm_log10f(h), histo_scale, histo_ofs, n_bins);
+}
+
+/* ---- sin / cos: stand in for native_sin / native_cos, fft.cl:66-67 ------- */
+/* Cody-Waite reduction by pi/2 in two pieces, degree-17/16 Taylor kernels in
+ * double on [-pi/4, pi/4], one rounding to float.  Intended for |x| < 1e5
+ * (the FFT only needs |x| < 2*pi). */
+static inline void fpm_sincos_core(float xf, double *s_out, double *c_out)
+{
+	static const double TWO_OVER_PI = 6.36619772367581382433e-01;
+	static const double PIO2_HI     = 1.57079632673412561417e+00;	/* 33 bits of pi/2 */
+	static const double PIO2_LO     = 6.07710050650619224932e-11;	/* pi/2 - PIO2_HI  */
+
+	double x = (double)xf;
+	double kd = floor(x * TWO_OVER_PI + 0.5);
+	double r  = (x - kd * PIO2_HI) - kd * PIO2_LO;
+	double r2 = r * r;
+	double ps, pc, s, c;
+	int q = (int)((int64_t)kd & 3);
+
+	ps = -1.0 / 355687428096000.0;			/* -1/17! */
+	ps = ps * r2 + 1.0 / 1307674368000.0;		/*  1/15! */
+	ps = ps * r2 - 1.0 / 6227020800.0;		/* -1/13! */
+	ps = ps * r2 + 1.0 / 39916800.0;		/*  1/11! */
+	ps = ps * r2 - 1.0 / 362880.0;			/* -1/9!  */
+	ps = ps * r2 + 1.0 / 5040.0;			/*  1/7!  */
+	ps = ps * r2 - 1.0 / 120.0;			/* -1/5!  */
+	ps = ps * r2 + 1.0 / 6.0;			/*  1/3!  */
+	s  = (r == 0.0) ? r : r - (r * r2) * ps;	/* keeps sin(-0) = -0 */
+
+	pc = 1.0 / 20922789888000.0;			/*  1/16! */
+	pc = pc * r2 - 1.0 / 87178291200.0;		/* -1/14! */
+	pc = pc * r2 + 1.0 / 479001600.0;		/*  1/12! */
+	pc = pc * r2 - 1.0 / 3628800.0;			/* -1/10! */
+	pc = pc * r2 + 1.0 / 40320.0;			/*  1/8!  */
+	pc = pc * r2 - 1.0 / 720.0;			/* -1/6!  */
+	pc = pc * r2 + 1.0 / 24.0;			/*  1/4!  */
+	pc = pc * r2 - 1.0 / 2.0;			/* -1/2!  */
+	c  = 1.0 + r2 * pc;
+
+	switch (q) {
+	case 0:  *s_out =  s; *c_out =  c; break;
+	case 1:  *s_out =  c; *c_out = -s; break;
+	case 2:  *s_out = -s; *c_out = -c; break;
+	default: *s_out = -c; *c_out =  s; break;
+	}
+}
+
+static inline float fpm_sinf(float x)
+{
+	double s, c;
+	fpm_sincos_core(x, &s, &c);
+	return (float)s;
+}
+
+static inline float fpm_cosf(float x)
+{
+	double s, c;
+	fpm_sincos_core(x, &s, &c);
+	return (float)c;
+}
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FOSPHOR_PORTABLE_MATH_H */
