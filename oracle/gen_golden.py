@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own kernels.
+
+TEST INFRASTRUCTURE.  Runs only in the build container: it needs
+oracle/_ref/libfosphor_ref.so, which oracle/Makefile (`make ref`) compiles from
+/root/reference/lib/fosphor/{fft.cl,display.cl} where they lie.  The fixtures are data
+(inputs + expected outputs); no reference source is stored.
+
+    python3 oracle/gen_golden.py            # regenerate everything
+    python3 oracle/gen_golden.py c1_gauss_b16
+
+Every fixture is produced with the "portable" built-in binding
+(include/fosphor_portable_math.h).  golden_meta.json additionally records, per case, how
+many hit-count cells / waterfall texels change when the reference kernels are bound to
+glibc's sinf/cosf/hypotf/log10f/roundf instead (informational: the libm sensitivity of an
+implementation-defined OpenCL runtime).
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import golden_cases as gc			# noqa: E402
+from oracle_lib import RefKernels, build_oracle, canon_bits, digest, hitcount_from_rows	# noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return digest(a)
+
+
+def written_rows(wf, pos0, batch):
+    idx = (pos0 + np.arange(min(batch, 1024))) & 1023
+    if batch > 1024:		# ring overwritten: last 1024 spectra survive (display.cl:142-146)
+        idx = (pos0 + np.arange(batch - 1024, batch)) & 1023
+    return idx, wf[idx]
+
+
+def run_case(name, spec, portable=True):
+    r = RefKernels(portable=portable)
+    if "power_range" in spec:
+        r.set_power_range(*spec["power_range"])
+    if "window" in spec:
+        r.set_window(spec["window"]())
+    out = []
+    for x in spec["calls"]():
+        pos0 = r.waterfall_pos
+        rv = r.process(x, strict=spec.get("strict", True))
+        assert rv == 0, (name, rv)
+        batch = x.shape[0] // 1024
+        wf = r.waterfall
+        idx, rows = written_rows(wf, pos0, batch)
+        # counts: every spectrum of THIS call, through its pwr row.  For batch <= 1024 all rows
+        # survive in the ring; for larger batches take them from the FFT output instead.
+        out.append(dict(x=x, batch=batch, pos0=pos0, pos1=r.waterfall_pos, fft=r.fft_out,
+                        wf_idx=idx, wf_rows=rows, wf=wf, hist=r.histogram, spec=r.spectrum,
+                        hs=r.histo_scale, ho=r.histo_offset))
+    return out
+
+
+def main(argv):
+    build_oracle(ref=True)
+    os.makedirs(OUT, exist_ok=True)
+    meta_path = os.path.join(OUT, "golden_meta.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    names = argv or list(gc.CASES)
+
+    for name in names:
+        spec = gc.CASES[name]
+        t0 = time.time()
+        res = run_case(name, spec, portable=True)
+        alt = run_case(name, spec, portable=False) if res[0]["batch"] <= 1024 else None
+        arrays, m = {}, {"calls": []}
+        for k, c in enumerate(res):
+            pre = "c%d_" % k
+            if c["batch"] <= 1024:
+                hc = hitcount_from_rows(c["wf_rows"], c["hs"], c["ho"], 128)
+            else:
+                hc = None
+            cm = dict(batch=c["batch"], pos0=c["pos0"], pos1=c["pos1"],
+                      hs=float(c["hs"]), ho=float(c["ho"]),
+                      sha_fft=sha(c["fft"]), sha_wf=sha(c["wf"]), sha_hist=sha(c["hist"]),
+                      sha_spec=sha(c["spec"]))
+            if hc is not None:
+                cm["sha_hc"] = sha(hc)
+                assert int(hc.sum()) == c["batch"] * 1024
+            if alt is not None:
+                a = alt[k]
+                hca = hitcount_from_rows(a["wf_rows"], a["hs"], a["ho"], 128)
+                cm["glibc_binding"] = dict(
+                    hitcount_cells_differ=int((hca != hc).sum()),
+                    waterfall_texels_differ=int((canon_bits(a["wf_rows"]) != canon_bits(c["wf_rows"])).sum()),
+                    fft_words_differ=int((canon_bits(a["fft"]) != canon_bits(c["fft"])).sum()),
+                    samples=int(c["batch"] * 1024))
+            m["calls"].append(cm)
+            if spec["store"] == "full":
+                arrays[pre + "x"] = c["x"]
+                arrays[pre + "fft"] = c["fft"]
+                arrays[pre + "wf_idx"] = c["wf_idx"].astype(np.int32)
+                arrays[pre + "wf_rows"] = c["wf_rows"]
+                arrays[pre + "hist"] = c["hist"]
+                arrays[pre + "spec"] = c["spec"]
+                arrays[pre + "hc"] = hc
+            elif k == len(res) - 1:
+                arrays[pre + "hist"] = c["hist"]
+                arrays[pre + "spec"] = c["spec"]
+                arrays[pre + "wf_row_sample_idx"] = c["wf_idx"][::97].astype(np.int32)
+                arrays[pre + "wf_row_sample"] = c["wf_rows"][::97]
+                if hc is not None:
+                    arrays[pre + "hc"] = hc
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+        meta[name] = m
+        print("%-22s %d call(s)  %.1fs" % (name, len(res), time.time() - t0), flush=True)
+
+    if not argv or "fft512" in argv:
+        x = gc.fft512_input()
+        y = RefKernels.fft(x, gc.hann512(), n=512)
+        np.savez_compressed(os.path.join(OUT, "fft512.npz"), x=x, win=gc.hann512(), fft=y)
+        meta["fft512"] = {"sha_fft": sha(y)}
+
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main([a for a in sys.argv[1:] if a in gc.CASES or a == "fft512"])
