@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's libfosphor interface over the HIP library.
+
+Same names and argument meaning as lib/fosphor/fosphor.h (process / draw / set_fft_window /
+set_power_range / set_frequency_range) plus the plain-buffer accessors that replace the
+CL<->GL interop.  Everything numeric happens in libfosphor_amd.so on the GPU; this class
+only marshals pointers.
+"""
+import ctypes as C
+import errno
+
+import numpy as np
+
+from . import _lib
+
+FFT_LEN_LOG = 10		# private.h:21
+FFT_LEN = 1 << FFT_LEN_LOG
+MULT_BATCH = 16			# private.h:24
+MAX_BATCH = 1024		# private.h:25
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor / anything with data_ptr(), or a raw integer."""
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class Fosphor:
+    """One fosphor instance (struct fosphor).  Reference geometry by default."""
+
+    def __init__(self, n_bins=128, wf_rows=1024, fft_len_log=FFT_LEN_LOG, t0r=0.0, t0d=0.0, alpha=0.0,
+                 device=-1, max_spectra=1024, max_batches=0, stream=None):
+        self.L = _lib.load()
+        cfg = _lib.Config(fft_len_log, n_bins, wf_rows, t0r, t0d, alpha, device, max_spectra, max_batches,
+                          C.c_void_p(stream) if stream else None)
+        self.h = self.L.fosphor_amd_init(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("fosphor_amd_init failed (see stderr); no CPU fallback exists")
+        self.n, self.n_bins, self.wf_rows = 1 << fft_len_log, n_bins, wf_rows
+        self.max_spectra = max_spectra
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fosphor_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API ---------------------------------------------------
+    def process(self, samples):
+        """fosphor_process: host interleaved fp32 (re, im); returns 0 / -EINVAL / -EIO."""
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        return self.L.fosphor_process(self.h, x.ctypes.data, x.size // 2)
+
+    def draw(self, render=None):
+        r = render if render is not None else _lib.Render()
+        self.L.fosphor_draw(self.h, C.byref(r))
+        return r._wf_pos
+
+    def set_fft_window_default(self):
+        self.L.fosphor_set_fft_window_default(self.h)
+
+    def set_fft_window(self, win):
+        w = np.ascontiguousarray(win, dtype=np.float32)
+        if w.size != self.n:
+            raise ValueError("window must have %d taps" % self.n)
+        self.L.fosphor_set_fft_window(self.h, w.ctypes.data)
+
+    def set_power_range(self, db_ref, db_per_div):
+        self.L.fosphor_set_power_range(self.h, int(db_ref), int(db_per_div))
+
+    def set_frequency_range(self, center, span):
+        self.L.fosphor_set_frequency_range(self.h, float(center), float(span))
+
+    # ---- device-resident data path -----------------------------------------
+    def process_device(self, d_samples, n_batches, batch):
+        return self.L.fosphor_amd_process_device(self.h, _ptr(d_samples), int(n_batches), int(batch))
+
+    def finish(self):
+        return self.L.fosphor_amd_finish(self.h)
+
+    def accumulate_device(self, d_samples, n_local, t_offset, total_batch):
+        return self.L.fosphor_amd_accumulate_device(self.h, _ptr(d_samples), n_local, t_offset, total_batch)
+
+    def merge(self, total_batch):
+        return self.L.fosphor_amd_merge(self.h, total_batch)
+
+    def partials(self):
+        p = _lib.Partials()
+        self.L.fosphor_amd_get_partials(self.h, C.byref(p))
+        return p
+
+    def buffers(self):
+        b = _lib.Buffers()
+        self.L.fosphor_amd_get_buffers(self.h, C.byref(b))
+        return b
+
+    # ---- results as host arrays ------------------------------------------
+    def _read(self, which, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        rv = self.L.fosphor_amd_read(self.h, which, out.ctypes.data, out.nbytes)
+        if rv:
+            raise RuntimeError("fosphor_amd_read(%d) -> %d (%s)" % (which, rv, errno.errorcode.get(-rv, "?")))
+        return out
+
+    @property
+    def waterfall(self):
+        return self._read(0, (self.wf_rows, self.n), np.float32)
+
+    @property
+    def histogram(self):
+        return self._read(1, (self.n_bins, self.n), np.float32)
+
+    @property
+    def spectrum(self):
+        return self._read(2, (2, self.n, 2), np.float32)
+
+    @property
+    def hitcount(self):
+        """uint32 [n_bins][N] of the last batch (the oracle's view is the transpose)."""
+        return self._read(3, (self.n_bins, self.n), np.uint32)
+
+    @property
+    def waterfall_pos(self):
+        return self.buffers().waterfall_pos
+
+    @property
+    def histo_scale(self):
+        return self.buffers().histo_scale
+
+    @property
+    def histo_offset(self):
+        return self.buffers().histo_offset
+
+    # ---- kernel-level hooks -------------------------------------------------
+    def fft_device(self, d_in, d_out, n_spectra):
+        return self.L.fosphor_amd_fft(self.h, _ptr(d_in), _ptr(d_out), n_spectra)
+
+    def bin_device(self, d_fft, d_bin, d_pwr, n):
+        return self.L.fosphor_amd_bin(self.h, _ptr(d_fft), _ptr(d_bin), _ptr(d_pwr), n)
+
+    # ---- measurement --------------------------------------------------------
+    def profile(self, enable=True):
+        self.L.fosphor_amd_profile(self.h, 1 if enable else 0)
+
+    def kernel_times(self):
+        ms = (C.c_float * 3)()
+        n = (C.c_int * 3)()
+        rv = self.L.fosphor_amd_kernel_times(self.h, C.byref(ms), C.byref(n))
+        if rv:
+            raise RuntimeError("fosphor_amd_kernel_times -> %d" % rv)
+        return list(ms), list(n)
+
+    @property
+    def stream(self):
+        return self.L.fosphor_amd_stream(self.h)

@@ -1,0 +1,713 @@
+/*
+ * fosphor_api.cpp -- C ABI of libfosphor_amd.so (include/fosphor.h, include/fosphor_amd.h)
+ *
+ * Host runtime that replaces lib/fosphor/cl.c + the compute half of
+ * lib/fosphor/fosphor.c: device buffers, lazy window upload (cl.c:889-900),
+ * first-run fills (cl.c:406-465), per-call launch sequence (cl.c:903-954),
+ * waterfall ring position (cl.c:954,1073-1079), histogram range (cl.c:1081-1089),
+ * tri-state BOOTING/PENDING/READY (cl.c:92-96), errno-style returns.
+ *
+ * There is no CPU fallback: without a HIP device fosphor_init() fails loudly.
+ */
+#include <errno.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "fosphor_internal.h"
+#include "../../include/fosphor_amd.h"
+#include "../../include/fosphor_portable_math.h"
+
+using namespace fosphor_amd;
+
+#define FOSPHOR_AMD_VERSION "fosphor_amd 0.1 gfx950"
+
+#define HIP_TRY(expr, what) do { \
+		hipError_t _e = (expr); \
+		if (_e != hipSuccess) { \
+			fprintf(stderr, "[!] fosphor_amd: %s: %s\n", what, hipGetErrorString(_e)); \
+			goto error; \
+		} \
+	} while (0)
+
+enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
+
+struct fosphor
+{
+	/* geometry / constants */
+	int log2n, n, n_bins, wf_rows;
+	float t0r, t0d, alpha;
+	int max_spectra, max_batches;
+
+	/* reference-visible settings (private.h:44-54) */
+	float fft_win[kN];
+	int   win_dirty;
+	struct { int db_ref, db_per_div; float scale, offset; } power;
+	struct { double center, span; } frequency;
+	float histo_scale, histo_offset;	/* cl.c:1087-1088 */
+	int   thr_dirty;
+
+	/* device */
+	int device;
+	hipStream_t stream;
+	int own_stream;
+	float    *d_win;
+	float2   *d_tw;
+	double   *d_thr;
+	float    *d_wf, *d_hist;
+	float2   *d_spectrum;
+	uint32_t *d_bins;
+	float2   *d_partial;
+	uint32_t *d_hc;
+	float    *d_live_sum, *d_vmax;
+	float2   *d_fft_tmp;			/* fosphor_amd_fft scratch is caller-provided; unused */
+
+	/* host->device staging for fosphor_process (pinned ring of 2) */
+	float2   *h_stage[2];
+	float2   *d_stage[2];
+	hipEvent_t stage_free[2];
+	int       stage_idx;
+	double   *h_thr;			/* pinned, n_bins+1 */
+	float    *h_win;			/* pinned, N */
+
+	/* state */
+	int state;
+	int wf_pos;
+	int last_batches;			/* batches in the most recent launch (hitcount view) */
+	int acc_total;				/* pending accumulate (multi-GPU split) */
+
+	/* profiling */
+	int prof;
+	std::vector<hipEvent_t> ev_pool;
+	std::vector<int> ev_kind;		/* kernel index per (start, stop) pair */
+	size_t ev_used;
+};
+
+/* ------------------------------------------------------------------------ */
+/* Host-side tables                                                         */
+/* ------------------------------------------------------------------------ */
+
+/* Twiddles exactly as the reference forms them (fft.cl:62-68,162-166,286-297), with
+ * native_sin/native_cos pinned to fosphor_portable_math.h */
+static void build_twiddles(float2 *tw)
+{
+	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
+	for (int pass = 0; pass < 2; pass++) {
+		const int p = pass ? 64 : 8;
+		float2 *dst = tw + (pass ? kTw3Off : kTw2Off);
+		for (int k = 0; k < p; k++) {
+			const float alpha = -PI_F * (float)k / (float)(4 * p);
+			for (int n = 1; n < 8; n++) {
+				const float arg = (float)n * alpha;
+				dst[k * 7 + (n - 1)] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+			}
+		}
+	}
+	for (int k = 0; k < 512; k++) {
+		const float alpha = -PI_F * (float)k / (float)(512);
+		const float arg = (float)1 * alpha;
+		tw[kTw4Off + k] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+	}
+}
+
+/* Exact bin thresholds on the double squared magnitude: thr[b] = smallest s >= 0 with
+ * oracle bin(s) >= b.  bin(s) is monotone while hypot(s) is finite (checked exhaustively by
+ * oracle/tools/pm_check.c); thr[nb] = smallest s whose hypot overflows float. */
+static void build_thresholds(double *thr, int nb, float hs, float ho)
+{
+	/* largest s with finite (float)sqrt(s) */
+	uint64_t lo = 0, hi = fpm_d2u(1.0e80);
+	while (hi - lo > 1) {
+		uint64_t mid = lo + (hi - lo) / 2;
+		if (isinf(fpm_hypot_from_sqmag(fpm_u2d(mid)))) hi = mid; else lo = mid;
+	}
+	const uint64_t s_inf = hi;
+	thr[0] = -1.0;
+	thr[nb] = fpm_u2d(s_inf);
+	for (int b = 1; b < nb; b++) {
+		/* invariant: bin(lo) < b <= bin(hi) on [0, s_inf) */
+		if (fpm_bin_from_sqmag(fpm_u2d(s_inf - 1), hs, ho, nb) < b) {
+			thr[b] = fpm_u2d(s_inf);	/* unreachable bin */
+			continue;
+		}
+		lo = 0; hi = s_inf - 1;
+		while (hi - lo > 1) {
+			uint64_t mid = lo + (hi - lo) / 2;
+			if (fpm_bin_from_sqmag(fpm_u2d(mid), hs, ho, nb) >= b) hi = mid; else lo = mid;
+		}
+		thr[b] = fpm_u2d(hi);
+	}
+}
+
+/* ------------------------------------------------------------------------ */
+/* Init / release                                                           */
+/* ------------------------------------------------------------------------ */
+
+extern "C" const char *fosphor_amd_version(void) { return FOSPHOR_AMD_VERSION; }
+
+extern "C" void fosphor_release(struct fosphor *self)
+{
+	if (!self)
+		return;
+	if (self->stream)
+		(void)hipStreamSynchronize(self->stream);
+	(void)hipFree(self->d_win); (void)hipFree(self->d_tw); (void)hipFree(self->d_thr);
+	(void)hipFree(self->d_wf); (void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
+	(void)hipFree(self->d_bins); (void)hipFree(self->d_partial); (void)hipFree(self->d_hc);
+	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
+	for (int i = 0; i < 2; i++) {
+		if (self->h_stage[i]) (void)hipHostFree(self->h_stage[i]);
+		if (self->d_stage[i]) (void)hipFree(self->d_stage[i]);
+		if (self->stage_free[i]) (void)hipEventDestroy(self->stage_free[i]);
+	}
+	if (self->h_thr) (void)hipHostFree(self->h_thr);
+	if (self->h_win) (void)hipHostFree(self->h_win);
+	for (hipEvent_t e : self->ev_pool) (void)hipEventDestroy(e);
+	if (self->own_stream && self->stream)
+		(void)hipStreamDestroy(self->stream);
+	delete self;
+}
+
+extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg)
+{
+	struct fosphor *self = new (std::nothrow) fosphor();
+	int ndev = 0;
+	size_t tiles_max;
+	std::vector<float2> tw(kTwLen);
+
+	if (!self)
+		return NULL;
+
+	self->log2n   = (cfg && cfg->fft_len_log > 0) ? cfg->fft_len_log : kLog2N;
+	self->n       = 1 << self->log2n;
+	self->n_bins  = (cfg && cfg->n_bins > 0) ? cfg->n_bins : 128;
+	self->wf_rows = (cfg && cfg->wf_rows > 0) ? cfg->wf_rows : 1024;
+	self->t0r     = (cfg && cfg->t0r > 0.0f) ? cfg->t0r : 16.0f;		/* cl.c:714 */
+	self->t0d     = (cfg && cfg->t0d > 0.0f) ? cfg->t0d : 1024.0f;		/* cl.c:715 */
+	self->alpha   = (cfg && cfg->alpha > 0.0f) ? cfg->alpha : 0.002f;	/* cl.c:716 */
+	self->max_spectra = (cfg && cfg->max_spectra > 0) ? cfg->max_spectra : 1024;
+	self->max_batches = (cfg && cfg->max_batches > 0) ? cfg->max_batches
+	                    : (self->max_spectra / 1024 > 8 ? self->max_spectra / 1024 : 8);
+
+	if (self->log2n != kLog2N) {
+		fprintf(stderr, "[!] fosphor_amd: fft_len_log=%d not supported (only %d)\n", self->log2n, kLog2N);
+		goto error;
+	}
+	if (self->n_bins < 16 || self->n_bins > 256 || (self->n_bins & 15)) {
+		fprintf(stderr, "[!] fosphor_amd: n_bins=%d not supported (16..256, multiple of 16)\n", self->n_bins);
+		goto error;
+	}
+	if (self->wf_rows & (self->wf_rows - 1)) {
+		fprintf(stderr, "[!] fosphor_amd: wf_rows=%d is not a power of two\n", self->wf_rows);
+		goto error;
+	}
+	if (self->max_spectra & 15) {
+		fprintf(stderr, "[!] fosphor_amd: max_spectra=%d is not a multiple of 16\n", self->max_spectra);
+		goto error;
+	}
+
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+		fprintf(stderr, "[!] fosphor_amd: no HIP device available (this library has no CPU path)\n");
+		goto error;
+	}
+	if (cfg && cfg->device >= 0) {
+		HIP_TRY(hipSetDevice(cfg->device), "hipSetDevice");
+		self->device = cfg->device;
+	} else {
+		HIP_TRY(hipGetDevice(&self->device), "hipGetDevice");
+	}
+
+	if (cfg && cfg->stream) {
+		self->stream = (hipStream_t)cfg->stream;
+	} else {
+		HIP_TRY(hipStreamCreateWithFlags(&self->stream, hipStreamNonBlocking), "hipStreamCreate");
+		self->own_stream = 1;
+	}
+
+	tiles_max = (size_t)self->max_spectra / 4;
+	HIP_TRY(hipMalloc((void **)&self->d_win, sizeof(float) * kN), "alloc window");
+	HIP_TRY(hipMalloc((void **)&self->d_tw, sizeof(float2) * kTwLen), "alloc twiddles");
+	HIP_TRY(hipMalloc((void **)&self->d_thr, sizeof(double) * (self->n_bins + 1)), "alloc thresholds");
+	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * kN), "alloc waterfall");
+	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * kN), "alloc histogram");
+	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * kN), "alloc spectrum");
+	HIP_TRY(hipMalloc((void **)&self->d_bins, (size_t)self->max_spectra * kN), "alloc bin indices");
+	HIP_TRY(hipMalloc((void **)&self->d_partial, sizeof(float2) * tiles_max * kN), "alloc partials");
+	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
+	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
+	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
+	HIP_TRY(hipHostMalloc((void **)&self->h_thr, sizeof(double) * (self->n_bins + 1), hipHostMallocDefault), "alloc pinned thr");
+	HIP_TRY(hipHostMalloc((void **)&self->h_win, sizeof(float) * kN, hipHostMallocDefault), "alloc pinned win");
+
+	build_twiddles(tw.data());
+	HIP_TRY(hipMemcpy(self->d_tw, tw.data(), sizeof(float2) * kTwLen, hipMemcpyHostToDevice), "upload twiddles");
+
+	/* Initial state (fosphor.c:64-66) */
+	fosphor_set_fft_window_default(self);
+	fosphor_set_power_range(self, 0, 10);
+	self->state = ST_BOOTING;
+	return self;
+
+error:
+	fosphor_release(self);
+	return NULL;
+}
+
+extern "C" struct fosphor *fosphor_init(void)
+{
+	return fosphor_amd_init(NULL);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Settings                                                                 */
+/* ------------------------------------------------------------------------ */
+
+extern "C" void fosphor_set_fft_window_default(struct fosphor *self)
+{
+	/* periodic Hamming x 1.855, fosphor.c:113-118 */
+	for (int i = 0; i < kN; i++) {
+		float ft = (float)kN;
+		float fp = (float)i;
+		self->fft_win[i] = (0.54f - 0.46f * cosf((2.0f * 3.141592f * fp) / ft)) * 1.855f;
+	}
+	self->win_dirty = 1;
+}
+
+extern "C" void fosphor_set_fft_window(struct fosphor *self, float *win)
+{
+	memcpy(self->fft_win, win, sizeof(float) * kN);		/* fosphor.c:123-128 */
+	self->win_dirty = 1;
+}
+
+extern "C" void fosphor_set_power_range(struct fosphor *self, int db_ref, int db_per_div)
+{
+	/* fosphor.c:131-152 */
+	int db0 = db_ref - 10 * db_per_div;
+	int db1 = db_ref;
+	float k = fpm_log10f((float)kN);
+	float offset = -(k + ((float)db0 / 20.0f));
+	float scale  = 20.0f / (float)(db1 - db0);
+
+	self->power.db_ref = db_ref;
+	self->power.db_per_div = db_per_div;
+	self->power.scale = scale;
+	self->power.offset = offset;
+
+	/* cl.c:1081-1089, with the bin count a parameter instead of 128 */
+	self->histo_scale  = scale * (float)self->n_bins;
+	self->histo_offset = offset;
+	self->thr_dirty = 1;
+}
+
+extern "C" void fosphor_set_frequency_range(struct fosphor *self, double center, double span)
+{
+	self->frequency.center = center;	/* fosphor.c:154-160 */
+	self->frequency.span   = span;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Launch sequence                                                          */
+/* ------------------------------------------------------------------------ */
+
+static void prof_begin(struct fosphor *self, int kind)
+{
+	if (!self->prof) return;
+	if (self->ev_used + 2 > self->ev_pool.size()) {
+		for (int i = 0; i < 2; i++) {
+			hipEvent_t e;
+			if (hipEventCreate(&e) != hipSuccess) return;
+			self->ev_pool.push_back(e);
+		}
+	}
+	self->ev_kind.push_back(kind);
+	(void)hipEventRecord(self->ev_pool[self->ev_used], self->stream);
+}
+
+static void prof_end(struct fosphor *self)
+{
+	if (!self->prof) return;
+	if (self->ev_used + 2 > self->ev_pool.size()) return;
+	(void)hipEventRecord(self->ev_pool[self->ev_used + 1], self->stream);
+	self->ev_used += 2;
+}
+
+/* Upload lazily-changed tables (cl.c:889-900) and boot fills (cl.c:406-465, 930-934) */
+static int prepare(struct fosphor *self)
+{
+	if (self->win_dirty) {
+		(void)hipStreamSynchronize(self->stream);	/* h_win may still be in flight */
+		memcpy(self->h_win, self->fft_win, sizeof(float) * kN);
+		HIP_TRY(hipMemcpyAsync(self->d_win, self->h_win, sizeof(float) * kN, hipMemcpyHostToDevice, self->stream), "upload window");
+		self->win_dirty = 0;
+	}
+	if (self->thr_dirty) {
+		(void)hipStreamSynchronize(self->stream);
+		build_thresholds(self->h_thr, self->n_bins, self->histo_scale, self->histo_offset);
+		HIP_TRY(hipMemcpyAsync(self->d_thr, self->h_thr, sizeof(double) * (self->n_bins + 1), hipMemcpyHostToDevice, self->stream), "upload thresholds");
+		self->thr_dirty = 0;
+	}
+	if (self->state == ST_BOOTING) {
+		const float noise_floor = -self->power.offset;
+		HIP_TRY(launch_fill((float *)self->d_spectrum, noise_floor, (size_t)4 * kN, self->stream), "fill spectrum");
+		HIP_TRY(launch_fill(self->d_wf, noise_floor, (size_t)self->wf_rows * kN, self->stream), "fill waterfall");
+		HIP_TRY(launch_fill(self->d_hist, 0.0f, (size_t)self->n_bins * kN, self->stream), "fill histogram");
+	}
+	return 0;
+error:
+	return -EIO;
+}
+
+static int pick_tile(int total)
+{
+	/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
+	if (total / 16 >= 2048) return 16;
+	if (total / 8 >= 2048) return 8;
+	return 4;
+}
+
+static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int total, int tile,
+                    int wf_pos0, int wf_first)
+{
+	const double A = (double)self->histo_scale * 0.150514997831990597606869447362;
+	const double C = (double)self->histo_scale * (double)self->histo_offset;
+	/* |v_fast - v_oracle| bound, see DESIGN.md "exact binning": a constant part from the
+	 * float roundings of v itself (v < 256) and a part proportional to histo_scale from
+	 * the log2 approximation on |log2 s| <= 32 */
+	const float delta = 6.0e-5f + 2.2e-6f * self->histo_scale;
+
+	memset(k1, 0, sizeof(*k1));
+	k1->iq = (const float2 *)d_iq;
+	k1->win = self->d_win;
+	k1->tw = self->d_tw;
+	k1->thr = self->d_thr;
+	k1->bins = self->d_bins;
+	k1->partial = self->d_partial;
+	k1->wf = self->d_wf;
+	k1->fft_out = NULL;
+	k1->total = total;
+	k1->tile = tile;
+	k1->wf_pos0 = wf_pos0;
+	k1->wf_mask = self->wf_rows - 1;
+	k1->wf_first = wf_first;
+	k1->n_bins = self->n_bins;
+	k1->binA = (float)A;
+	k1->binC = (float)C;
+	k1->amb = 0.5f - delta;
+	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
+}
+
+static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
+{
+	const int total = n_batches * batch;
+	const int tile = pick_tile(total);
+	K1Params k1; K2Params k2; K3Params k3;
+
+	if (prepare(self))
+		return -EIO;
+
+	fill_k1(self, &k1, d_iq, total, tile, self->wf_pos,
+	        total > self->wf_rows ? total - self->wf_rows : 0);
+	prof_begin(self, 0);
+	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
+	prof_end(self);
+
+	memset(&k2, 0, sizeof(k2));
+	k2.bins = self->d_bins; k2.partial = self->d_partial;
+	k2.hc = self->d_hc; k2.live_sum = self->d_live_sum; k2.vmax = self->d_vmax;
+	k2.batch = batch; k2.tile = tile; k2.n_bins = self->n_bins; k2.w = k1.w;
+	k2.t_offset = 0; k2.weight_batch = batch;
+	prof_begin(self, 1);
+	HIP_TRY(launch_k2(k2, n_batches, self->stream), "launch count");
+	prof_end(self);
+
+	memset(&k3, 0, sizeof(k3));
+	k3.hc = self->d_hc; k3.live_sum = self->d_live_sum; k3.vmax = self->d_vmax;
+	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
+	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins;
+	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
+	prof_begin(self, 2);
+	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
+	prof_end(self);
+
+	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
+	self->last_batches = n_batches;
+	self->state = ST_PENDING;
+	return 0;
+error:
+	return -EIO;
+}
+
+extern "C" int fosphor_amd_process_device(struct fosphor *self, const void *d_samples, int n_batches, int batch)
+{
+	if (!self || !d_samples || n_batches < 1 || batch < 16 || (batch & 15))
+		return -EINVAL;
+	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
+		return -EINVAL;
+	return run(self, d_samples, n_batches, batch);
+}
+
+extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
+{
+	int k;
+
+	/* cl.c:882-886 */
+	if (len <= 0 || (len & ((16 * kN) - 1)))
+		return -EINVAL;
+	if (len > (kN * 1024))
+		return -EINVAL;
+	if (len / kN > self->max_spectra)
+		return -EINVAL;
+
+	/* cl.c:903-910 enqueues a non-blocking write straight from the caller's memory, which the
+	 * sink reuses immediately (base_sink_c_impl.cc:168-174: a latent race).  Here the samples
+	 * are copied into a pinned ring slot before returning, and the slot is recycled only when
+	 * its H2D copy has completed. */
+	k = self->stage_idx;
+	if (!self->h_stage[k]) {
+		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sizeof(float2) * kN * 1024, hipHostMallocDefault), "alloc pinned staging");
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * kN * 1024), "alloc device staging");
+		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
+	} else {
+		HIP_TRY(hipEventSynchronize(self->stage_free[k]), "wait staging slot");
+	}
+	memcpy(self->h_stage[k], samples, sizeof(float2) * (size_t)len);
+	HIP_TRY(hipMemcpyAsync(self->d_stage[k], self->h_stage[k], sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples");
+	{
+		int rv = run(self, self->d_stage[k], 1, len / kN);
+		/* the slot is free again once everything queued so far (copy + kernels reading
+		 * d_stage[k]) has finished */
+		(void)hipEventRecord(self->stage_free[k], self->stream);
+		self->stage_idx ^= 1;
+		return rv;
+	}
+error:
+	return -EIO;
+}
+
+extern "C" int fosphor_amd_finish(struct fosphor *self)
+{
+	if (self->state == ST_READY)
+		return 0;				/* cl.c:977-979 */
+	if (self->state == ST_BOOTING) {		/* cl.c:981-995: finish the boot */
+		if (prepare(self))
+			return -EIO;
+	}
+	if (hipStreamSynchronize(self->stream) != hipSuccess)
+		return -EIO;
+	self->state = ST_READY;
+	return 1;
+}
+
+extern "C" void fosphor_draw(struct fosphor *self, struct fosphor_render *render)
+{
+	(void)fosphor_amd_finish(self);			/* fosphor.c:100-101 */
+	if (render)
+		render->_wf_pos = self->wf_pos;		/* fosphor.c:103 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* Buffers                                                                  */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out)
+{
+	if (!self || !out)
+		return -EINVAL;
+	out->d_waterfall = self->d_wf;
+	out->d_histogram = self->d_hist;
+	out->d_spectrum  = (float *)self->d_spectrum;
+	out->d_hitcount  = self->d_hc + (size_t)(self->last_batches > 0 ? self->last_batches - 1 : 0) * self->n_bins * kN;
+	out->waterfall_pos = self->wf_pos;
+	out->fft_len = kN; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
+	out->histo_scale = self->histo_scale; out->histo_offset = self->histo_offset;
+	return 0;
+}
+
+extern "C" int fosphor_amd_read(struct fosphor *self, int which, void *host, uint64_t bytes)
+{
+	struct fosphor_amd_buffers b;
+	const void *src; uint64_t want;
+	int rv;
+
+	if (!self || !host)
+		return -EINVAL;
+	rv = fosphor_amd_finish(self);
+	if (rv < 0)
+		return rv;
+	fosphor_amd_get_buffers(self, &b);
+	switch (which) {
+	case 0: src = b.d_waterfall; want = sizeof(float) * (uint64_t)self->wf_rows * kN; break;
+	case 1: src = b.d_histogram; want = sizeof(float) * (uint64_t)self->n_bins * kN; break;
+	case 2: src = b.d_spectrum;  want = sizeof(float) * 4 * kN; break;
+	case 3: src = b.d_hitcount;  want = sizeof(uint32_t) * (uint64_t)self->n_bins * kN; break;
+	default: return -EINVAL;
+	}
+	if (bytes != want)
+		return -EINVAL;
+	if (hipMemcpy(host, src, want, hipMemcpyDeviceToHost) != hipSuccess)
+		return -EIO;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Test hooks                                                               */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_out, int n_spectra)
+{
+	K1Params k1;
+	int saved_state;
+	if (!self || !d_in || !d_out || n_spectra < 4 || (n_spectra & 3) || n_spectra > self->max_spectra)
+		return -EINVAL;
+	saved_state = self->state;
+	self->state = ST_READY;			/* no boot fills for a pure FFT */
+	if (prepare(self)) { self->state = saved_state; return -EIO; }
+	self->state = saved_state;
+	/* rows are not stored (wf_first = total); bins/partials land in scratch */
+	fill_k1(self, &k1, d_in, n_spectra, 4, 0, n_spectra);
+	k1.fft_out = (float2 *)d_out;
+	if (launch_k1(k1, self->stream) != hipSuccess)
+		return -EIO;
+	return hipStreamSynchronize(self->stream) == hipSuccess ? 0 : -EIO;
+}
+
+extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *d_pwr, int n)
+{
+	K1Params k1;
+	int saved_state, force = 0;
+	const char *e = getenv("FOSPHOR_AMD_FORCE_EXACT_BIN");
+	if (!self || !d_fft || !d_bin || !d_pwr || n < 1)
+		return -EINVAL;
+	if (e && *e == '1') force = 1;
+	saved_state = self->state;
+	self->state = ST_READY;
+	if (prepare(self)) { self->state = saved_state; return -EIO; }
+	self->state = saved_state;
+	fill_k1(self, &k1, NULL, 0, 4, 0, 0);
+	if (launch_bin_hook((const float2 *)d_fft, (uint8_t *)d_bin, (float *)d_pwr, n, k1, force, self->stream) != hipSuccess)
+		return -EIO;
+	return hipStreamSynchronize(self->stream) == hipSuccess ? 0 : -EIO;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Multi-GPU split                                                          */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
+                                             int n_local, int t_offset, int total_batch)
+{
+	K1Params k1; K2Params k2;
+	int tile, wf_first;
+
+	if (!self || !d_samples || n_local < 16 || (n_local & 15) || (t_offset & 15) ||
+	    t_offset < 0 || t_offset + n_local > total_batch || n_local > self->max_spectra)
+		return -EINVAL;
+	if (prepare(self))
+		return -EIO;
+
+	tile = pick_tile(n_local);
+	/* global spectrum index tau = t_offset + t stores its row iff tau >= total_batch - wf_rows */
+	wf_first = total_batch - self->wf_rows - t_offset;
+	if (wf_first < 0) wf_first = 0;
+	fill_k1(self, &k1, d_samples, n_local, tile, (self->wf_pos + t_offset) & (self->wf_rows - 1), wf_first);
+	prof_begin(self, 0);
+	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
+	prof_end(self);
+
+	memset(&k2, 0, sizeof(k2));
+	k2.bins = self->d_bins; k2.partial = self->d_partial;
+	k2.hc = self->d_hc; k2.live_sum = self->d_live_sum; k2.vmax = self->d_vmax;
+	k2.batch = n_local; k2.tile = tile; k2.n_bins = self->n_bins; k2.w = k1.w;
+	k2.t_offset = t_offset; k2.weight_batch = total_batch;
+	prof_begin(self, 1);
+	HIP_TRY(launch_k2(k2, 1, self->stream), "launch count");
+	prof_end(self);
+
+	self->acc_total = total_batch;
+	self->state = ST_PENDING;
+	return 0;
+error:
+	return -EIO;
+}
+
+extern "C" int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd_partials *out)
+{
+	if (!self || !out)
+		return -EINVAL;
+	out->d_hc = self->d_hc;
+	out->d_live_sum = self->d_live_sum;
+	out->d_max = self->d_vmax;
+	out->n_hc = self->n_bins * kN;
+	out->n_cols = kN;
+	return 0;
+}
+
+extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
+{
+	K3Params k3;
+	if (!self || total_batch < 16)
+		return -EINVAL;
+	if (prepare(self))
+		return -EIO;
+	memset(&k3, 0, sizeof(k3));
+	k3.hc = self->d_hc; k3.live_sum = self->d_live_sum; k3.vmax = self->d_vmax;
+	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
+	k3.n_batches = 1; k3.batch = total_batch; k3.n_bins = self->n_bins;
+	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
+	prof_begin(self, 2);
+	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
+	prof_end(self);
+	self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
+	self->last_batches = 1;
+	self->state = ST_PENDING;
+	return 0;
+error:
+	return -EIO;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Measurement                                                              */
+/* ------------------------------------------------------------------------ */
+
+extern "C" void fosphor_amd_profile(struct fosphor *self, int enable)
+{
+	self->prof = enable ? 1 : 0;
+}
+
+extern "C" int fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3])
+{
+	if (!self)
+		return -EINVAL;
+	if (hipStreamSynchronize(self->stream) != hipSuccess)
+		return -EIO;
+	for (int i = 0; i < 3; i++) { ms[i] = 0.0f; launches[i] = 0; }
+	for (size_t i = 0; i + 1 < self->ev_used; i += 2) {
+		float t = 0.0f;
+		int kind = self->ev_kind[i / 2];
+		if (hipEventElapsedTime(&t, self->ev_pool[i], self->ev_pool[i + 1]) == hipSuccess) {
+			ms[kind] += t;
+			launches[kind]++;
+		}
+	}
+	self->ev_used = 0;
+	self->ev_kind.clear();
+	return 0;
+}
+
+extern "C" void *fosphor_amd_stream(struct fosphor *self)
+{
+	return self ? (void *)self->stream : NULL;
+}
+
+/* private accessor for fosphor_render.cpp (keeps struct fosphor opaque there) */
+extern "C" void fosphor_amd_priv_ranges(struct fosphor *self, int *db_ref, int *db_per_div,
+                                        double *center, double *span)
+{
+	*db_ref = self->power.db_ref;
+	*db_per_div = self->power.db_per_div;
+	*center = self->frequency.center;
+	*span = self->frequency.span;
+}

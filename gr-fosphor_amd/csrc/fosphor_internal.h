@@ -1,0 +1,84 @@
+/*
+ * fosphor_internal.h -- shared between the kernel TU and the C-ABI TU
+ */
+#ifndef FOSPHOR_INTERNAL_H
+#define FOSPHOR_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fosphor_amd {
+
+constexpr int kLog2N = 10;		/* FOSPHOR_FFT_LEN_LOG, private.h:21 */
+constexpr int kN     = 1 << kLog2N;
+
+/* Twiddle table layout (float2 entries), generated on the host with the pinned
+ * sin/cos of include/fosphor_portable_math.h from the exact float expressions
+ * of fft.cl:62-68,162-166,286-297:
+ *   [kTw2Off + k*7 + (n-1)]  pass 2 (p=8):  k in [0,8),  n in [1,8)
+ *   [kTw3Off + k*7 + (n-1)]  pass 3 (p=64): k in [0,64), n in [1,8)
+ *   [kTw4Off + k]            pass 4 (p=512, radix 2): k in [0,512)            */
+constexpr int kTw2Off = 0;
+constexpr int kTw3Off = kTw2Off + 8 * 7;
+constexpr int kTw4Off = kTw3Off + 64 * 7;
+constexpr int kTwLen  = kTw4Off + 512;
+
+constexpr int kK1MaxBlocks = 512;	/* 256 CUs x 2 resident work-groups of 4 waves */
+
+/* K1: IQ -> FFT -> bin index / waterfall row / live+max partials */
+struct K1Params {
+	const float2 *iq;		/* [total][N] */
+	const float  *win;		/* [N] */
+	const float2 *tw;		/* [kTwLen] */
+	const double *thr;		/* [n_bins + 1] exact squared-magnitude thresholds */
+	uint32_t     *bins;		/* [total/4][N], 4 consecutive spectra packed per dword */
+	float2       *partial;		/* [total/tile][N] (live partial, max) */
+	float        *wf;		/* [wf_rows][N] */
+	float2       *fft_out;		/* test hook, or nullptr */
+	int   total;			/* spectra in this launch */
+	int   tile;			/* spectra per wave: 4, 8 or 16 */
+	int   wf_pos0, wf_mask;		/* ring position of spectrum 0, wf_rows-1 */
+	int   wf_first;			/* spectra with index < wf_first do not store their row */
+	int   n_bins;
+	float binA, binC;		/* v ~= binA * log2(|X|^2) + binC */
+	float amb;			/* confident when |v - rint(v)| <= amb */
+	float w;			/* 1 - alpha */
+};
+
+/* K2: bin indices -> hit counts + per-batch live sum / max per column */
+struct K2Params {
+	const uint32_t *bins;		/* [total/4][N] */
+	const float2   *partial;	/* [total/tile][N] */
+	uint32_t *hc;			/* [n_batches][n_bins][N] */
+	float    *live_sum;		/* [n_batches][N] */
+	float    *vmax;			/* [n_batches][N] */
+	int   batch;			/* spectra per batch */
+	int   tile;
+	int   n_bins;
+	float w;
+	/* sharded batch (multi-GPU): this launch holds spectra [t_offset, t_offset+batch)
+	 * of a batch of weight_batch spectra; single GPU: t_offset 0, weight_batch = batch */
+	int   t_offset, weight_batch;
+};
+
+/* K3: histogram rise/decay, live EMA, max-hold */
+struct K3Params {
+	const uint32_t *hc;		/* [n_batches][n_bins][N] */
+	const float    *live_sum;	/* [n_batches][N] */
+	const float    *vmax;		/* [n_batches][N] */
+	float  *hist;			/* [n_bins][N] */
+	float2 *spectrum;		/* [2][N] */
+	int   n_batches, batch, n_bins;
+	float t0r, t0d, alpha;
+};
+
+hipError_t launch_k1(const K1Params &p, hipStream_t s);
+hipError_t launch_k2(const K2Params &p, int n_batches, hipStream_t s);
+hipError_t launch_k3(const K3Params &p, hipStream_t s);
+hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
+hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
+                           const K1Params &p, int force_exact, hipStream_t s);
+
+} // namespace fosphor_amd
+
+#endif

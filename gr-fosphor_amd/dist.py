@@ -1,0 +1,95 @@
+"""Multi-GPU frame: one process per GPU, time-sharded batch, per-frame RCCL all-reduce.
+
+SURVEY 8e: the spectra of one batch are independent through FFT, log-power and binning; all
+cross-spectrum coupling is a commutative reduction per column --
+    hit counts  hc[bin][x]   uint32, SUM   (order-independent -> bit-exact on any ring/tree)
+    live sum    S[x]         float,  SUM   (weights use the GLOBAL time index)
+    max         M[x]         float,  MAX
+after which every rank applies the identical merge kernel (K3) to identical inputs, so the
+persistent state is replicated bit-identically.  Waterfall rows stay with the rank that
+computed them.  torch.distributed ("nccl" = RCCL on ROCm) is the transport; the payload at
+1024 x 128 is 0.52 MiB, i.e. latency-bound on xGMI, so the three arrays go out as one
+coalesced group per frame.
+"""
+import numpy as np
+
+
+class _DeviceArray:
+    """Minimal __cuda_array_interface__ holder so torch can view library-owned HBM."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+        }
+
+
+_TYPESTR = {"torch.int32": "<i4", "torch.float32": "<f4", "torch.uint8": "|u1"}
+
+
+def wrap_device_array(ptr, shape, dtype):
+    """torch tensor aliasing `ptr` (no copy).  dtype: torch.int32 / float32 / uint8."""
+    import torch
+    return torch.as_tensor(_DeviceArray(ptr, shape, _TYPESTR[str(dtype)]), device="cuda")
+
+
+def allreduce_partials(hc, live_sum, vmax, group=None):
+    """The per-frame exchange.  Tensors are reduced in place; works on any backend
+    (RCCL on GPU tensors, gloo on CPU tensors in the tests).  hc must be an integer tensor
+    (uint32 counts viewed as int32: sums stay below 2^31 for any batch < 2^31 spectra)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    works = [
+        dist.all_reduce(hc, op=dist.ReduceOp.SUM, group=group, async_op=True),
+        dist.all_reduce(live_sum, op=dist.ReduceOp.SUM, group=group, async_op=True),
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=group, async_op=True),
+    ]
+    for w in works:
+        w.wait()
+
+
+def shard_range(total_batch, rank, world):
+    """Contiguous time block of a batch for one rank (each a multiple of 16 spectra)."""
+    if total_batch % (16 * world):
+        raise ValueError("batch %d does not split into %d shards of whole 16-spectrum groups" % (total_batch, world))
+    n = total_batch // world
+    return rank * n, n
+
+
+class ShardedFosphor:
+    """One rank's half of a sharded fosphor instance.
+
+    frame(d_samples_local, total_batch): K1+K2 on the local shard, all-reduce, K3.
+    The semantics are one reference display launch with fft_batch = total_batch (the kernel
+    is batch-generic; only the host caps it, cl.c:885).
+    """
+
+    def __init__(self, fosphor_cls, rank, world, group=None, **kw):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        # run the library on torch's current stream so the collective is ordered after K2
+        # and K3 after the collective without host synchronisation
+        self.f = fosphor_cls(stream=torch.cuda.current_stream().cuda_stream, **kw)
+        p = self.f.partials()
+        self.hc = wrap_device_array(p.d_hc, (p.n_hc,), torch.int32)
+        self.live = wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32)
+        self.vmax = wrap_device_array(p.d_max, (p.n_cols,), torch.float32)
+
+    def frame(self, d_samples_local, total_batch):
+        off, n = shard_range(total_batch, self.rank, self.world)
+        rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)
+        if rv:
+            raise RuntimeError("accumulate_device -> %d" % rv)
+        allreduce_partials(self.hc, self.live, self.vmax, self.group)
+        rv = self.f.merge(total_batch)
+        if rv:
+            raise RuntimeError("merge -> %d" % rv)
+
+
+def combine_partials_numpy(parts):
+    """Reference combination rule on host arrays: [(hc, live, max), ...] -> (hc, live, max)."""
+    hc = np.sum([p[0].astype(np.uint64) for p in parts], axis=0).astype(np.uint32)
+    live = np.sum([p[1].astype(np.float32) for p in parts], axis=0, dtype=np.float32)
+    vmax = np.max([p[2] for p in parts], axis=0)
+    return hc, live, vmax

@@ -1,0 +1,140 @@
+/*
+ * fosphor_amd.h -- MI355X extensions next to the drop-in API of fosphor.h
+ *
+ * C ABI only: plain pointers and sizes, no C++/torch types.  These entry points
+ * are what the severed CL<->GL interop requires (SURVEY 8b "new export"):
+ * the reference kept its results in GL objects or in private host mirrors
+ * (private.h:40-42, cl.c:1003-1049); here they are plain HBM buffers.
+ *
+ * Pipeline per launch:
+ *   K1 fft_bin   IQ -> windowed Stockham FFT (fft.cl:397-466, bit-identical
+ *                arithmetic) -> exact histogram bin index per sample (u8),
+ *                waterfall rows, per-tile live/max partials
+ *   K2 count     bin indices -> integer hit counts hc[bin][x] (display.cl:161-177)
+ *                + per-batch live sum / max per column (display.cl:139,149-150)
+ *   K3 merge     histogram rise/decay, live EMA, max-hold (display.cl:186-310)
+ * Between K2 and K3 the three arrays {hc (u32, sum), live_sum (f32, sum),
+ * max (f32, max)} are exactly what a multi-GPU run all-reduces.
+ */
+#ifndef FOSPHOR_AMD_H
+#define FOSPHOR_AMD_H
+
+#include <stdint.h>
+
+#include "fosphor.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Geometry and kernel constants.  Zero / negative fields take the reference
+ * defaults: fft_len_log 10 (private.h:21), n_bins 128 (display.cl:96),
+ * wf_rows 1024 (cl.c:528), t0r 16, t0d 1024, alpha 0.002 (cl.c:714-716). */
+struct fosphor_amd_config
+{
+	int   fft_len_log;	/* 10 supported in this round */
+	int   n_bins;		/* 16..256, multiple of 16 */
+	int   wf_rows;		/* power of two */
+	float t0r, t0d, alpha;
+	int   device;		/* HIP device ordinal; -1 = current */
+	int   max_spectra;	/* capacity of one launch (all batches together); 0 = 1024 */
+	int   max_batches;	/* most batches in one launch; 0 = max(8, max_spectra/1024) */
+	void *stream;		/* hipStream_t to run on; NULL = create a private one */
+};
+
+/* fosphor_init with explicit geometry.  NULL on failure (message on stderr). */
+struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg);
+
+/* Process IQ that is ALREADY in device memory: n_batches consecutive batches of
+ * `batch` spectra each (batch % 16 == 0), interleaved fp32 (re, im).
+ * Semantics are identical to n_batches successive fosphor_process() calls of
+ * batch*N samples each (cl.c:870-968) -- every batch gets its own histogram /
+ * live / max-hold update in order -- but the FFT+binning of all batches runs
+ * as one launch.  Waterfall rows that a later spectrum of the same call
+ * overwrites are not stored (the ring ends in the same state).
+ * batch is not capped at 1024: the reference's cap is host-side only
+ * (cl.c:885); a larger batch means one display launch with that fft_batch.
+ * Returns 0, -EINVAL (bad sizes / over capacity), -EIO (device error). */
+int fosphor_amd_process_device(struct fosphor *self, const void *d_samples,
+                               int n_batches, int batch);
+
+/* Wait for queued work; counterpart of fosphor_cl_finish (cl.c:970-1061):
+ * 1 = new results, 0 = nothing was pending, -EIO = device error. */
+int fosphor_amd_finish(struct fosphor *self);
+
+/* Plain-buffer view of the results.  Layouts are the reference's host mirrors
+ * (private.h:40-42, fosphor.c:54-56), generalised to the configured geometry:
+ *   waterfall  float[wf_rows][N]   x = unshifted FFT bin (DC at 0), ring in y
+ *   histogram  float[n_bins][N]    row = dB bin (0 = bottom), x unshifted
+ *   spectrum   float[2][N][2]      live then max-hold; (x, y) vertices,
+ *                                  index = bin ^ N/2 (fft-shifted)
+ *   hitcount   uint32[n_bins][N]   integer counts of the LAST batch processed
+ * Pointers are device pointers, valid until fosphor_release. */
+struct fosphor_amd_buffers
+{
+	float    *d_waterfall;
+	float    *d_histogram;
+	float    *d_spectrum;
+	uint32_t *d_hitcount;
+	int       waterfall_pos;	/* cl.c:1073-1079 */
+	int       fft_len, n_bins, wf_rows;
+	float     histo_scale, histo_offset;	/* cl.c:1087-1088 */
+};
+int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out);
+
+/* Host copies (synchronise first).  which: 0 waterfall, 1 histogram, 2 spectrum,
+ * 3 hitcount.  `bytes` must equal the buffer size.  0 / -EINVAL / -EIO. */
+int fosphor_amd_read(struct fosphor *self, int which, void *host, uint64_t bytes);
+
+/* Kernel-level test hook: windowed forward FFT only (the fft1D_1024 contract,
+ * fft.cl:397-466): d_in, d_out are float2[n_spectra][N] device buffers. */
+int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_out, int n_spectra);
+
+/* Kernel-level test hook: per-sample bin index and approximate log-power of FFT
+ * outputs already in device memory: d_fft float2[n], d_bin uint8[n], d_pwr float[n]. */
+int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *d_pwr, int n);
+
+/* ---- multi-GPU split (one process per GPU; exchange done by the caller) --- */
+
+/* Rank-local half of ONE batch of `total_batch` spectra that is sharded over
+ * ranks in contiguous time blocks: this rank holds spectra
+ * [t_offset, t_offset + n_local).  Runs K1+K2 and leaves the three partial
+ * arrays in device memory; nothing persistent is updated except this rank's
+ * waterfall rows. */
+int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
+                                  int n_local, int t_offset, int total_batch);
+
+/* The partial arrays to all-reduce: hc uint32[n_bins][N] (sum),
+ * live_sum float[N] (sum), max float[N] (max). */
+struct fosphor_amd_partials
+{
+	uint32_t *d_hc;
+	float    *d_live_sum;
+	float    *d_max;
+	int       n_hc, n_cols;
+};
+int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd_partials *out);
+
+/* Apply K3 with the (reduced) partial arrays as one batch of total_batch
+ * spectra, and advance the waterfall ring by total_batch. */
+int fosphor_amd_merge(struct fosphor *self, int total_batch);
+
+/* ---- measurement ---------------------------------------------------------- */
+
+/* When enabled, every K1/K2/K3 launch is bracketed by hipEvents on the
+ * instance's stream.  fosphor_amd_kernel_times synchronises, returns the summed
+ * milliseconds and launch counts per kernel since the last call, and resets. */
+void fosphor_amd_profile(struct fosphor *self, int enable);
+int  fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3]);
+
+/* hipStream_t the instance runs on. */
+void *fosphor_amd_stream(struct fosphor *self);
+
+/* Library identification: "fosphor_amd <version> gfx950". */
+const char *fosphor_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FOSPHOR_AMD_H */

@@ -300,6 +300,17 @@ int fosphor_oracle_bin(float re, float im, float hs, float ho, int n_bins)
 	return fpm_bin_from_pwr(pwr, hs, ho, n_bins);	/* display.cl:161-168 */
 }
 
+/* Vectorised form for kernel-level tests: bin index and log-power of n FFT outputs */
+void fosphor_oracle_bins(const float *fft, int n, float hs, float ho, int n_bins, int32_t *bin, float *pwr)
+{
+	int i;
+	for (i = 0; i < n; i++) {
+		float p = fpm_log10f(fpm_hypotf(fft[2 * i], fft[2 * i + 1]));
+		pwr[i] = p;
+		bin[i] = fpm_bin_from_pwr(p, hs, ho, n_bins);
+	}
+}
+
 /* One display work-group = 16 consecutive columns (display.cl:67, cl.c:945-950).
  * x0 = first column.  Everything below follows display.cl line by line with
  * the 16x16 local geometry kept, because the float summation orders of

@@ -61,6 +61,7 @@ class Oracle:
             L.fosphor_oracle_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
             L.fosphor_oracle_fft.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.fosphor_oracle_bin.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+            L.fosphor_oracle_bins.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
             for n in ("waterfall", "histogram", "spectrum", "fft_out"):
                 f = getattr(L, "fosphor_oracle_" + n)
                 f.restype = _fp
@@ -166,6 +167,16 @@ class Oracle:
     @classmethod
     def bin(cls, re, im, hs, ho, n_bins=128):
         return cls.lib().fosphor_oracle_bin(re, im, hs, ho, n_bins)
+
+
+def oracle_bins(fft, hs, ho, n_bins=128):
+    """(bin int32[n], pwr float32[n]) of FFT outputs float32[n][2] through the pinned pipeline."""
+    L = Oracle.lib()
+    f = _as_f32(fft).reshape(-1, 2)
+    b = np.empty(f.shape[0], np.int32)
+    p = np.empty(f.shape[0], np.float32)
+    L.fosphor_oracle_bins(f.ctypes.data, f.shape[0], hs, ho, n_bins, b.ctypes.data, p.ctypes.data)
+    return b, p
 
 
 class RefKernels:

@@ -1,0 +1,370 @@
+"""GPU: parity of the HIP path (through the C ABI of libfosphor_amd.so) against the oracle
+and the reference-generated golden fixtures.
+
+Bars (BASELINE.json north_star):
+  * integer hit counts            bit-exact
+  * FFT output                    bit-exact (same arithmetic order as fft.cl, contraction off)
+  * waterfall / live / max-hold   rtol 1e-4 (atol 1e-6: log10|X| crosses zero at |X| = 1)
+  * persistence histogram floats  atol 2e-6 on values in [0, 1]
+Nothing here reads /root/reference.
+"""
+import errno
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+from oracle_lib import Oracle, canon_bits, gaussian_iq, add_tone, oracle_bins
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+META = json.load(open(os.path.join(GOLD, "golden_meta.json")))
+
+RTOL, ATOL = 1e-4, 1e-6
+HIST_ATOL = 2e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from _pkg import gr_fosphor_amd
+    gr_fosphor_amd.load()		# hard error when the HIP library is missing
+    return gr_fosphor_amd
+
+
+def close_float(a, b, rtol=RTOL, atol=ATOL):
+    """allclose with inf == inf and nan == nan (position-wise)."""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    same_special = (np.isnan(a) & np.isnan(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)))
+    fin = np.isfinite(a) & np.isfinite(b)
+    ok = same_special | (fin & (np.abs(a - b) <= atol + rtol * np.abs(b)))
+    return ok
+
+
+def assert_close(a, b, what, rtol=RTOL, atol=ATOL):
+    ok = close_float(a, b, rtol, atol)
+    if not ok.all():
+        idx = np.argwhere(~ok)[:5]
+        a = np.asarray(a); b = np.asarray(b)
+        msg = ", ".join("%s: %r vs %r" % (tuple(i), a[tuple(i)], b[tuple(i)]) for i in idx)
+        raise AssertionError("%s: %d / %d outside tolerance; first: %s" % (what, (~ok).sum(), ok.size, msg))
+
+
+def assert_hist_close(h_gpu, h_ref, what):
+    """Persistence histogram.  Cells the fast-exit rule (display.cl:237-238, hv <= 0.01 and no
+    hits -> not rewritten) treats differently because the two float states straddle 0.01 by
+    rounding are excused -- they are listed and must be rare."""
+    d = np.abs(h_gpu - h_ref)
+    bad = d > HIST_ATOL + RTOL * np.abs(h_ref)
+    if bad.any():
+        near_exit = np.abs(h_ref - 0.01) < 2e-4
+        hard = bad & ~near_exit
+        assert not hard.any(), "%s: %d cells differ (max %g)" % (what, hard.sum(), d[hard].max())
+        assert bad.sum() <= max(2, bad.size // 20000), "%s: %d cells straddle the 0.01 fast-exit" % (what, bad.sum())
+
+
+def compare_state(f, o, what, wf_rows=None):
+    """HIP instance f vs oracle o after the same calls."""
+    assert f.waterfall_pos == o.waterfall_pos, what
+    hc_gpu = f.hitcount			# [bin][x]
+    hc_ref = o.hitcount.T		# oracle is [x][bin]
+    assert np.array_equal(hc_gpu, hc_ref), "%s: hit counts differ in %d cells" % (what, (hc_gpu != hc_ref).sum())
+    wf_g, wf_o = f.waterfall, o.waterfall
+    if wf_rows is not None:
+        wf_g, wf_o = wf_g[wf_rows], wf_o[wf_rows]
+    assert_close(wf_g, wf_o, what + " waterfall")
+    sp_g, sp_o = f.spectrum, o.spectrum
+    assert np.array_equal(canon_bits(sp_g[..., 0]), canon_bits(sp_o[..., 0])), what + " vertex x"
+    assert_close(sp_g[0, :, 1], sp_o[0, :, 1], what + " live")
+    assert_close(sp_g[1, :, 1], sp_o[1, :, 1], what + " max-hold")
+    assert_hist_close(f.histogram, o.histogram, what + " histogram")
+
+
+# ---------------------------------------------------------------------------
+# kernel level
+# ---------------------------------------------------------------------------
+
+def test_fft_bit_exact(amd, torch_cuda, oracle_built):
+    torch = torch_cuda
+    f = amd.Fosphor(max_spectra=256)
+    o = Oracle()
+    x = gaussian_iq(64 * 1024, 77, sigma=1.0).reshape(64, 1024, 2)
+    x[5] *= 1e-3
+    x[6] *= 1e3
+    x[7] = 0.0
+    x[8, 3, 0] = np.inf
+    x[9, 900, 1] = np.nan
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    assert f.fft_device(d_in, d_out, 64) == 0
+    got = d_out.cpu().numpy()
+    want = Oracle.fft(x, o.window)
+    assert np.array_equal(canon_bits(got), canon_bits(want)), \
+        "%d words differ" % (canon_bits(got) != canon_bits(want)).sum()
+    # custom window
+    w = gc.blackman_harris()
+    f.set_fft_window(w)
+    assert f.fft_device(d_in, d_out, 64) == 0
+    assert np.array_equal(canon_bits(d_out.cpu().numpy()), canon_bits(Oracle.fft(x, w)))
+    f.close()
+
+
+def _bin_inputs(o, n_bins):
+    """Random magnitudes over 60 decades + every float around every bin edge + specials."""
+    rng = np.random.default_rng(5)
+    n = 1 << 21
+    mag = np.exp(rng.uniform(np.log(1e-30), np.log(1e30), n))
+    ph = rng.uniform(0, 2 * np.pi, n)
+    rnd = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 1).astype(np.float32)
+    # mid-range, dense (the regime real spectra live in)
+    mag = np.exp(rng.uniform(np.log(1e-4), np.log(1e3), n))
+    ph = rng.uniform(0, 2 * np.pi, n)
+    mid = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 1).astype(np.float32)
+    # bin edges: bisect on float bit patterns of h with (re, im) = (h, 0), then sweep +-64 ulps,
+    # and also hit the same |X| off-axis
+    hs, ho = o.histo_scale, o.histo_offset
+    edges = []
+    for b in range(1, n_bins):
+        lo, hi = np.uint32(1), np.uint32(0x7F000000)
+        while hi - lo > 1:
+            mid_u = np.uint32((int(lo) + int(hi)) // 2)
+            h = np.array([mid_u], np.uint32).view(np.float32)[0]
+            if Oracle.bin(h, 0.0, hs, ho, n_bins) >= b:
+                hi = mid_u
+            else:
+                lo = mid_u
+        edges.append(int(hi))
+    sweep = (np.array(edges, np.int64)[:, None] + np.arange(-64, 65)[None, :]).reshape(-1)
+    hsw = sweep.astype(np.uint32).view(np.float32)
+    on_axis = np.stack([hsw, np.zeros_like(hsw)], 1)
+    c, s = np.float32(0.6), np.float32(0.8)
+    off_axis = np.stack([hsw * c, hsw * s], 1).astype(np.float32)
+    special = np.array([[0, 0], [np.inf, 0], [0, -np.inf], [np.nan, 1], [np.inf, np.nan], [1e-45, 0],
+                        [1e-40, 1e-41], [3e38, 3e38], [1e20, 1e20], [-1e-20, 1e-20], [1, 0], [0, -1],
+                        [2e19, 0], [1.8e19, 1e18]], np.float32)
+    return np.concatenate([rnd, mid, on_axis, off_axis, special]).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_bins,power", [(128, (0, 10)), (256, (0, 10)), (128, (-20, 5)), (256, (10, 2))])
+def test_bin_exact(amd, torch_cuda, oracle_built, n_bins, power):
+    torch = torch_cuda
+    f = amd.Fosphor(n_bins=n_bins)
+    o = Oracle(n_bins=n_bins)
+    f.set_power_range(*power)
+    o.set_power_range(*power)
+    assert f.histo_scale == o.histo_scale and f.histo_offset == o.histo_offset
+    v = _bin_inputs(o, n_bins)
+    d = torch.from_numpy(v).cuda()
+    d_bin = torch.empty(v.shape[0], dtype=torch.uint8, device="cuda")
+    d_pwr = torch.empty(v.shape[0], dtype=torch.float32, device="cuda")
+    want_bin, want_pwr = oracle_bins(v, o.histo_scale, o.histo_offset, n_bins)
+    for force in ("0", "1"):
+        os.environ["FOSPHOR_AMD_FORCE_EXACT_BIN"] = force
+        assert f.bin_device(d, d_bin, d_pwr, v.shape[0]) == 0
+        got = d_bin.cpu().numpy().astype(np.int32)
+        bad = got != want_bin
+        assert not bad.any(), "force=%s: %d bins differ, e.g. %r -> gpu %d oracle %d" % (
+            force, bad.sum(), v[np.argmax(bad)], got[np.argmax(bad)], want_bin[np.argmax(bad)])
+        assert_close(d_pwr.cpu().numpy(), want_pwr, "pwr (force=%s)" % force)
+    os.environ.pop("FOSPHOR_AMD_FORCE_EXACT_BIN", None)
+    f.close()
+
+
+# ---------------------------------------------------------------------------
+# whole path through fosphor_process(), against the reference fixtures
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", [n for n in gc.CASES if gc.CASES[n]["store"] == "full"])
+def test_process_matches_reference_fixture(amd, torch_cuda, name):
+    spec = gc.CASES[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    f = amd.Fosphor()
+    if "power_range" in spec:
+        f.set_power_range(*spec["power_range"])
+    if "window" in spec:
+        f.set_fft_window(spec["window"]())
+    for k in range(len(META[name]["calls"])):
+        m = META[name]["calls"][k]
+        pre = "c%d_" % k
+        assert f.process(z[pre + "x"]) == 0
+        assert f.draw() == m["pos1"]
+        assert np.array_equal(f.hitcount, z[pre + "hc"].T), "%s call %d: hit counts" % (name, k)
+        assert_close(f.waterfall[z[pre + "wf_idx"]], z[pre + "wf_rows"], "%s call %d waterfall" % (name, k))
+        sp = f.spectrum
+        assert_close(sp[0, :, 1], z[pre + "spec"][0, :, 1], "%s call %d live" % (name, k))
+        assert_close(sp[1, :, 1], z[pre + "spec"][1, :, 1], "%s call %d max-hold" % (name, k))
+        assert np.array_equal(canon_bits(sp[..., 0]), canon_bits(z[pre + "spec"][..., 0]))
+        assert_hist_close(f.histogram, z[pre + "hist"], "%s call %d histogram" % (name, k))
+    f.close()
+
+
+def test_untouched_waterfall_rows_keep_noise_floor(amd, torch_cuda):
+    f = amd.Fosphor()
+    assert f.process(gaussian_iq(16 * 1024, 1)) == 0
+    wf = f.waterfall
+    assert np.all(wf[16:] == np.float32(-f.histo_offset))	# cl.c:406-433: noise floor = -power.offset
+    f.close()
+
+
+def test_process_argument_errors(amd, torch_cuda):
+    """cl.c:882-886 error behaviour through the C ABI."""
+    f = amd.Fosphor()
+    assert f.process(np.zeros((17 * 1024, 2), np.float32)) == -errno.EINVAL
+    assert f.process(np.zeros((1040 * 1024, 2), np.float32)) == -errno.EINVAL
+    assert f.waterfall_pos == 0
+    assert f.finish() == 1		# boot fills pending (cl.c:981-995)
+    assert f.finish() == 0		# nothing pending (cl.c:977-979)
+    assert f.process(np.zeros((16 * 1024, 2), np.float32)) == 0
+    assert f.finish() == 1
+    f.close()
+
+
+@pytest.mark.parametrize("n_bins", [128, 256])
+def test_stateful_sequence_vs_oracle(amd, torch_cuda, oracle_built, n_bins):
+    """Six calls of mixed batch sizes with a drifting tone: state carry-over, ring advance."""
+    f = amd.Fosphor(n_bins=n_bins)
+    o = Oracle(n_bins=n_bins)
+    t0 = 0
+    for k, b in enumerate([16, 48, 1024, 32, 512, 64]):
+        x = add_tone(gaussian_iq(b * 1024, 100 + k), 0.1, 0.05 + 0.01 * k, t0=t0)
+        t0 += b * 1024
+        assert f.process(x) == 0 and o.process(x, nthreads=8) == 0
+        compare_state(f, o, "call %d (batch %d, %d bins)" % (k, b, n_bins))
+    f.close()
+
+
+def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_built):
+    """fosphor_amd_process_device(n_batches, batch) == n_batches fosphor_process calls."""
+    torch = torch_cuda
+    nbat, b = 5, 64
+    x = add_tone(gaussian_iq(nbat * b * 1024, 42), 0.3, 0.2)
+    f = amd.Fosphor(max_spectra=nbat * b)
+    o = Oracle()
+    d = torch.from_numpy(x).cuda()
+    assert f.process_device(d, nbat, b) == 0
+    for k in range(nbat):
+        assert o.process(x[k * b * 1024:(k + 1) * b * 1024], nthreads=8) == 0
+    compare_state(f, o, "5 x 64")
+    # a second launch continues from the carried state, and wraps the ring (5*64*2 = 640 < 1024: add more)
+    x2 = gaussian_iq(8 * 128 * 1024, 43)
+    f2 = amd.Fosphor(max_spectra=8 * 128)
+    o2 = Oracle()
+    assert f2.process_device(torch.from_numpy(x2).cuda(), 8, 128) == 0
+    for k in range(8):
+        assert o2.process(x2[k * 128 * 1024:(k + 1) * 128 * 1024], nthreads=8) == 0
+    compare_state(f2, o2, "8 x 128 (full ring)")
+    f.close(); f2.close()
+
+
+def test_ring_overwrite_within_one_launch(amd, torch_cuda, oracle_built):
+    """More spectra than waterfall rows in one launch: the last wf_rows spectra survive, exactly
+    as after the equivalent sequence of reference calls."""
+    torch = torch_cuda
+    x = gaussian_iq(3 * 512 * 1024, 44)
+    f = amd.Fosphor(max_spectra=3 * 512)
+    o = Oracle()
+    f.process(gaussian_iq(16 * 1024, 45)); o.process(gaussian_iq(16 * 1024, 45))	# offset the ring
+    assert f.process_device(torch.from_numpy(x).cuda(), 3, 512) == 0
+    for k in range(3):
+        o.process(x[k * 512 * 1024:(k + 1) * 512 * 1024], nthreads=8)
+    compare_state(f, o, "3 x 512 over a 1024-row ring")
+    f.close()
+
+
+def test_big_batch_digest_fixture(amd, torch_cuda):
+    """One display launch with fft_batch = 8192 (the multi-GPU semantics) against the
+    reference-kernel fixture."""
+    torch = torch_cuda
+    z = np.load(os.path.join(GOLD, "c8_b8192.npz"))
+    x = gc.CASES["c8_b8192"]["calls"]()[0]
+    f = amd.Fosphor(max_spectra=8192)
+    assert f.process_device(torch.from_numpy(x).cuda(), 1, 8192) == 0
+    assert f.finish() == 1
+    assert_hist_close(f.histogram, z["c0_hist"], "b8192 histogram")
+    assert_close(f.spectrum[0, :, 1], z["c0_spec"][0, :, 1], "b8192 live")
+    assert_close(f.spectrum[1, :, 1], z["c0_spec"][1, :, 1], "b8192 max-hold")
+    assert_close(f.waterfall[z["c0_wf_row_sample_idx"]], z["c0_wf_row_sample"], "b8192 waterfall sample")
+    hc = f.hitcount
+    assert np.all(hc.sum(0) == 8192)
+    f.close()
+
+
+def test_full_size_properties(amd, torch_cuda):
+    """BASELINE config C2 size (batch 1024, 256 bins), 4 batches per launch: size-independent
+    properties -- counts sum to the batch per column, determinism, and hit-count additivity
+    (counts of a 2048-batch = sum of the counts of its two 1024-halves)."""
+    torch = torch_cuda
+    x = gaussian_iq(2048 * 1024, 46)
+    d = torch.from_numpy(x).cuda()
+    f = amd.Fosphor(n_bins=256, max_spectra=4096)
+    assert f.process_device(d, 2, 1024) == 0
+    hc_b = f.hitcount.astype(np.int64)			# second half
+    assert np.all(hc_b.sum(0) == 1024)
+    g = amd.Fosphor(n_bins=256, max_spectra=4096)
+    assert g.process_device(d, 1, 1024) == 0
+    hc_a = g.hitcount.astype(np.int64)			# first half
+    h = amd.Fosphor(n_bins=256, max_spectra=4096)
+    assert h.process_device(d, 1, 2048) == 0
+    assert np.array_equal(h.hitcount.astype(np.int64), hc_a + hc_b)
+    # determinism: same input, same launch -> identical bits everywhere
+    f2 = amd.Fosphor(n_bins=256, max_spectra=4096)
+    assert f2.process_device(d, 2, 1024) == 0
+    assert np.array_equal(canon_bits(f.histogram), canon_bits(f2.histogram))
+    assert np.array_equal(canon_bits(f.waterfall), canon_bits(f2.waterfall))
+    assert np.array_equal(canon_bits(f.spectrum), canon_bits(f2.spectrum))
+    for q in (f, g, h, f2):
+        q.close()
+
+
+def test_sharded_batch_equals_single_launch(amd, torch_cuda, oracle_built):
+    """The multi-GPU split run on one device: two 'ranks' each accumulate half of one 2048-spectrum
+    batch, the partial arrays are combined the way the all-reduce would (sum, sum, max), one merge:
+    identical counts and matching floats vs the single-launch path and vs the oracle."""
+    torch = torch_cuda
+    total = 2048
+    x = add_tone(gaussian_iq(total * 1024, 47), 0.05, 0.31)
+    d = torch.from_numpy(x).cuda()
+    ranks = [amd.Fosphor(max_spectra=total) for _ in range(2)]
+    parts = []
+    for r, fr in enumerate(ranks):
+        off = r * (total // 2)
+        assert fr.accumulate_device(d[off * 1024:(off + total // 2) * 1024], total // 2, off, total) == 0
+        fr.finish()
+        parts.append(fr.partials())
+    # combine on the device with torch (stand-in for RCCL all-reduce)
+    from gr_fosphor_amd.dist import wrap_device_array
+    hc = [wrap_device_array(p.d_hc, (p.n_hc,), torch.int32) for p in parts]
+    ls = [wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32) for p in parts]
+    mx = [wrap_device_array(p.d_max, (p.n_cols,), torch.float32) for p in parts]
+    hc_sum = hc[0] + hc[1]
+    ls_sum = ls[0] + ls[1]
+    mx_max = torch.maximum(mx[0], mx[1])
+    for r in range(2):
+        hc[r].copy_(hc_sum); ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
+    torch.cuda.synchronize()
+    for fr in ranks:
+        assert fr.merge(total) == 0
+    o = Oracle()
+    assert o.process(x, strict=False, nthreads=8) == 0
+    # rank 0 holds rows of the first half only; compare hist/spectrum/counts
+    for fr in ranks:
+        assert np.array_equal(fr.hitcount, o.hitcount.T)
+        assert_hist_close(fr.histogram, o.histogram, "sharded histogram")
+        assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "sharded live")
+        assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "sharded max-hold")
+        assert fr.waterfall_pos == o.waterfall_pos
+    # waterfall rows: rank 1 owns the last 1024 spectra = the whole surviving ring
+    assert_close(ranks[1].waterfall, o.waterfall, "sharded waterfall (rank 1 rows)")
+    for fr in ranks:
+        fr.close()
