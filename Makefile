@@ -18,7 +18,7 @@ HDRS := $(CSRC)/fosphor_internal.h include/fosphor.h include/fosphor_amd.h inclu
 
 all: $(LIB)
 
-$(LIB): $(SRCS) $(HDRS)
+$(LIB): $(SRCS) $(HDRS) Makefile
 	$(HIPCC) $(HIPFLAGS) -x hip -shared -o $@ $(SRCS)
 
 oracle:

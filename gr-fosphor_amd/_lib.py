@@ -101,6 +101,15 @@ def load():
             raise RuntimeError(
                 "gr-fosphor_amd: %s is missing -- run `make` (or __graft_entry__.build()); "
                 "there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (SONAME
+        # libamdhip64.so.7, like /opt/rocm's) but libtorch_hip asks for it by the unversioned
+        # file name, so if THIS library is loaded first (pulling in /opt/rocm's copy) a later
+        # `import torch` loads a second runtime and device init fails.  Importing torch first
+        # makes both bind to the one runtime, so pointers, streams and events are shared.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)		# AttributeError = the library does not export the header's symbol

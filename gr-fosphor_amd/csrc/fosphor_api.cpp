@@ -209,9 +209,13 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		goto error;
 	}
 
-	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
-		fprintf(stderr, "[!] fosphor_amd: no HIP device available (this library has no CPU path)\n");
-		goto error;
+	{
+		hipError_t e = hipGetDeviceCount(&ndev);
+		if (e != hipSuccess || ndev < 1) {
+			fprintf(stderr, "[!] fosphor_amd: no HIP device available (%s, %d devices); this library has no CPU path\n",
+			        hipGetErrorString(e), ndev);
+			goto error;
+		}
 	}
 	if (cfg && cfg->device >= 0) {
 		HIP_TRY(hipSetDevice(cfg->device), "hipSetDevice");

@@ -122,8 +122,8 @@ static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float p
 			}
 			bin = lo;
 		}
-		if (__builtin_isinf(re) || __builtin_isinf(im)) {
-			*pwr_out = __builtin_inff();		/* hypot(inf, anything) = inf */
+		if (__builtin_isinf(re) || __builtin_isinf(im) || sd >= thr[nb]) {
+			*pwr_out = __builtin_inff();		/* hypot(inf, anything) = inf; float hypot overflow */
 		} else if (sd == 0.0) {
 			*pwr_out = -__builtin_inff();		/* log10(0) */
 		} else if (sd != sd) {
