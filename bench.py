@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: complex IQ MSamples/s through the fosphor hot path at 1024-pt FFT.
+
+Contract (one JSON line on rank 0):
+    python bench.py --gpus N --steps K --warmup W
+    N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A STEP is one batch of 1024 spectra x 1024 points (1 Mi complex samples, 8 MiB of fp32 IQ) per
+GPU, already resident in HBM, taken through the whole path: windowed FFT -> log-power -> exact
+histogram bin -> hit counts -> persistence-histogram rise/decay, live EMA, max-hold, waterfall.
+Workload = BASELINE.json configs[1] ("C2": 1024-pt FFT, batch=1024, 1024x256 histogram +
+waterfall, 1xMI355X); per-GPU work is the same at every N (weak scaling, configs[3] "C4").
+
+  N = 1  ("batch" mode): every step gets its own state update, exactly like successive
+         fosphor_process() calls of the reference (cl.c:870-968); steps are submitted
+         --batches-per-launch at a time (fosphor_amd_process_device), which changes launch
+         granularity, not results.
+  N > 1  ("frame" mode): the spectra of a display frame (--batches-per-launch steps per GPU) are
+         time-sharded over the ranks; hit counts / live sums / max are all-reduced over RCCL once
+         per frame and every rank applies the same state update.  The all-reduce of
+         frame k overlaps the FFT of frame k+1.
+
+The input ring is larger than the 256 MiB Infinity Cache so IQ reads come from HBM.
+
+roofline: the dominant kernel is K1 (fft_bin).  achieved = 8 B x samples per launch / mean K1
+duration, measured with hipEvents on the library's stream inside the timed region.
+cpu_baseline: the oracle (oracle/fosphor_oracle.c, the CPU restatement of the reference's
+fft.cl + display.cl) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+N_FFT = 1024
+BATCH = 1024
+HBM_PEAK_GBS = 8000.0		# MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+BYTES_PER_SAMPLE = 8		# algorithmic read, one complex fp32 sample
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1280)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--batches-per-launch", type=int, default=64)
+    ap.add_argument("--ring-batches", type=int, default=128, help="distinct batches of IQ resident in HBM (8 MiB each)")
+    ap.add_argument("--mode", choices=["auto", "batch", "frame"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(bins, seconds):
+    """Oracle (CPU restatement of the reference kernels) on all host cores, bounded sample."""
+    import numpy as np
+    from oracle_lib import Oracle, build_oracle, gaussian_iq
+    build_oracle(ref=False)
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, 64)			# the display stage has 64 column groups (cl.c:945-950)
+    o = Oracle(n_bins=bins)
+    x = gaussian_iq(BATCH * N_FFT, 7)
+    o.process(x, nthreads=nthreads)		# warm-up, page in
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        o.process(x, nthreads=nthreads)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 4096:
+            break
+    return {"value": n * BATCH * N_FFT / el / 1e6, "unit": "MSamples/s", "cores": nthreads, "kind": "port",
+            "sample": "%d batches of %d x %d-pt spectra (%.1f s), oracle C restatement of fft.cl+display.cl, "
+                      "%d threads of %d host cores" % (n, BATCH, N_FFT, el, nthreads, cores)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from _pkg import gr_fosphor_amd
+    from gr_fosphor_amd.dist import ShardedFosphor
+
+    mode = args.mode if args.mode != "auto" else ("batch" if world == 1 else "frame")
+    F = max(1, args.batches_per_launch)
+    ring = max(F, (args.ring_batches // F) * F)
+
+    # synthetic white complex Gaussian IQ, sigma 0.05 per component, resident in HBM
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7 + rank)
+    iq = torch.empty((ring * BATCH * N_FFT, 2), dtype=torch.float32, device="cuda")
+    iq.normal_(0.0, 0.05, generator=g)
+    samples_per_batch = BATCH * N_FFT
+
+    stream = torch.cuda.current_stream().cuda_stream
+    if mode == "batch":
+        f = gr_fosphor_amd.Fosphor(n_bins=args.bins, max_spectra=F * BATCH, max_batches=F, stream=stream)
+        sf = None
+    else:
+        sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, n_bins=args.bins, max_spectra=F * BATCH)
+        f = sf.f
+
+    def run_steps(n_steps, pos):
+        """submit n_steps batches starting at ring position pos; returns new pos"""
+        done = 0
+        while done < n_steps:
+            nb = min(F, n_steps - done)
+            if pos + nb > ring:
+                pos = 0
+            view = iq[pos * samples_per_batch:(pos + nb) * samples_per_batch]
+            if mode == "batch":
+                rv = f.process_device(view, nb, BATCH)
+                if rv:
+                    raise RuntimeError("process_device -> %d" % rv)
+            else:
+                sf.frame(view, nb * BATCH * world, overlap=True)
+            pos += nb
+            done += nb
+        if sf is not None:
+            sf.flush()
+        return pos
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pos = run_steps(args.warmup, 0)
+    sync()
+    f.profile(True)
+    t0 = time.perf_counter()
+    run_steps(args.steps, pos)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ms, launches = f.kernel_times()
+    f.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_samples = world * args.steps * samples_per_batch
+    value = total_samples / elapsed / 1e6
+
+    if rank == 0:
+        k1_ms = ms[0] / max(1, launches[0])
+        samples_per_launch = args.steps * samples_per_batch / max(1, launches[0])
+        achieved = BYTES_PER_SAMPLE * samples_per_launch / (k1_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("batches_per_launch") == F and j.get("bins") == args.bins:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "complex IQ MSamples/s @1024-pt FFT",
+            "value": value, "unit": "MSamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "C2: 1024-pt FFT, batch=1024 spectra/step/GPU, 1024x%d histogram + waterfall" % args.bins,
+                "mode": mode, "batches_per_launch": F, "ring_batches": ring,
+                "input": "white complex Gaussian sigma=0.05, fp32 IQ resident in HBM (%d MiB ring)" % (ring * 8),
+                "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d steps" % F,
+            },
+            "roofline": {"bound": "hbm", "kernel": "k1_fft_bin", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
+                         "k2_ms_per_launch": ms[1] / max(1, launches[1]),
+                         "k3_ms_per_launch": ms[2] / max(1, launches[2]),
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,9 @@ class Fosphor:
     def merge(self, total_batch):
         return self.L.fosphor_amd_merge(self.h, total_batch)
 
+    def set_partial_slot(self, slot):
+        return self.L.fosphor_amd_set_partial_slot(self.h, slot)
+
     def partials(self):
         p = _lib.Partials()
         self.L.fosphor_amd_get_partials(self.h, C.byref(p))

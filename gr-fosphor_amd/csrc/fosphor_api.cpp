@@ -63,6 +63,8 @@ struct fosphor
 	float2   *d_partial;
 	uint32_t *d_hc;
 	float    *d_live_sum, *d_vmax;
+	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
+	int       slot;				/* partial-array slot used by accumulate/merge */
 	float2   *d_fft_tmp;			/* fosphor_amd_fft scratch is caller-provided; unused */
 
 	/* host->device staging for fosphor_process (pinned ring of 2) */
@@ -77,6 +79,7 @@ struct fosphor
 	int state;
 	int wf_pos;
 	int last_batches;			/* batches in the most recent launch (hitcount view) */
+	int last_slot0;
 	int acc_total;				/* pending accumulate (multi-GPU split) */
 
 	/* profiling */
@@ -158,6 +161,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_wf); (void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
 	(void)hipFree(self->d_bins); (void)hipFree(self->d_partial); (void)hipFree(self->d_hc);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
+	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	for (int i = 0; i < 2; i++) {
 		if (self->h_stage[i]) (void)hipHostFree(self->h_stage[i]);
 		if (self->d_stage[i]) (void)hipFree(self->d_stage[i]);
@@ -243,6 +247,8 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
 	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
+	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk sums");
+	HIP_TRY(hipMalloc((void **)&self->d_chunk_max, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk max");
 	HIP_TRY(hipHostMalloc((void **)&self->h_thr, sizeof(double) * (self->n_bins + 1), hipHostMallocDefault), "alloc pinned thr");
 	HIP_TRY(hipHostMalloc((void **)&self->h_win, sizeof(float) * kN, hipHostMallocDefault), "alloc pinned win");
 
@@ -403,11 +409,71 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
 }
 
+static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+/* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
+ * d_bins / d_partial; results land in slot `slot0`.. of hc / live_sum / vmax. */
+static int run_count(struct fosphor *self, int n_batches, int batch, int tile, int slot0,
+                     int t_offset, int weight_batch)
+{
+	K2Params k2; K2bParams k2b;
+	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
+	const int cpb = batch / chunk;
+	const size_t cells = (size_t)self->n_bins * kN;
+
+	memset(&k2, 0, sizeof(k2));
+	k2.bins = self->d_bins; k2.partial = self->d_partial;
+	k2.hc = self->d_hc + (size_t)slot0 * cells;
+	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
+	k2.w = 1.0f - self->alpha;
+	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
+	if (cpb == 1) {
+		k2.chunk_sum = self->d_live_sum + (size_t)slot0 * kN;
+		k2.chunk_max = self->d_vmax + (size_t)slot0 * kN;
+	} else {
+		k2.chunk_sum = self->d_chunk_sum;
+		k2.chunk_max = self->d_chunk_max;
+		HIP_TRY(hipMemsetAsync(k2.hc, 0, sizeof(uint32_t) * cells * n_batches, self->stream), "zero hit counts");
+	}
+	prof_begin(self, 1);
+	HIP_TRY(launch_k2(k2, n_batches * cpb, self->stream), "launch count");
+	if (cpb > 1) {
+		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
+		k2b.live_sum = self->d_live_sum + (size_t)slot0 * kN;
+		k2b.vmax = self->d_vmax + (size_t)slot0 * kN;
+		k2b.n_batches = n_batches; k2b.cpb = cpb;
+		HIP_TRY(launch_k2b(k2b, self->stream), "launch chunk reduce");
+	}
+	prof_end(self);
+	return 0;
+error:
+	return -EIO;
+}
+
+static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0)
+{
+	K3Params k3;
+	const size_t cells = (size_t)self->n_bins * kN;
+	memset(&k3, 0, sizeof(k3));
+	k3.hc = self->d_hc + (size_t)slot0 * cells;
+	k3.live_sum = self->d_live_sum + (size_t)slot0 * kN;
+	k3.vmax = self->d_vmax + (size_t)slot0 * kN;
+	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
+	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins;
+	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
+	prof_begin(self, 2);
+	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
+	prof_end(self);
+	return 0;
+error:
+	return -EIO;
+}
+
 static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
 {
 	const int total = n_batches * batch;
 	const int tile = pick_tile(total);
-	K1Params k1; K2Params k2; K3Params k3;
+	K1Params k1;
 
 	if (prepare(self))
 		return -EIO;
@@ -418,26 +484,14 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
 	prof_end(self);
 
-	memset(&k2, 0, sizeof(k2));
-	k2.bins = self->d_bins; k2.partial = self->d_partial;
-	k2.hc = self->d_hc; k2.live_sum = self->d_live_sum; k2.vmax = self->d_vmax;
-	k2.batch = batch; k2.tile = tile; k2.n_bins = self->n_bins; k2.w = k1.w;
-	k2.t_offset = 0; k2.weight_batch = batch;
-	prof_begin(self, 1);
-	HIP_TRY(launch_k2(k2, n_batches, self->stream), "launch count");
-	prof_end(self);
-
-	memset(&k3, 0, sizeof(k3));
-	k3.hc = self->d_hc; k3.live_sum = self->d_live_sum; k3.vmax = self->d_vmax;
-	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
-	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins;
-	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
-	prof_begin(self, 2);
-	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
-	prof_end(self);
+	if (run_count(self, n_batches, batch, tile, 0, 0, batch))
+		return -EIO;
+	if (run_merge(self, n_batches, batch, 0))
+		return -EIO;
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
 	self->last_batches = n_batches;
+	self->last_slot0 = 0;
 	self->state = ST_PENDING;
 	return 0;
 error:
@@ -523,7 +577,7 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 	out->d_waterfall = self->d_wf;
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
-	out->d_hitcount  = self->d_hc + (size_t)(self->last_batches > 0 ? self->last_batches - 1 : 0) * self->n_bins * kN;
+	out->d_hitcount  = self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * kN;
 	out->waterfall_pos = self->wf_pos;
 	out->fft_len = kN; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
 	out->histo_scale = self->histo_scale; out->histo_offset = self->histo_offset;
@@ -603,7 +657,7 @@ extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_
 extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
                                              int n_local, int t_offset, int total_batch)
 {
-	K1Params k1; K2Params k2;
+	K1Params k1;
 	int tile, wf_first;
 
 	if (!self || !d_samples || n_local < 16 || (n_local & 15) || (t_offset & 15) ||
@@ -621,15 +675,12 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
 	prof_end(self);
 
-	memset(&k2, 0, sizeof(k2));
-	k2.bins = self->d_bins; k2.partial = self->d_partial;
-	k2.hc = self->d_hc; k2.live_sum = self->d_live_sum; k2.vmax = self->d_vmax;
-	k2.batch = n_local; k2.tile = tile; k2.n_bins = self->n_bins; k2.w = k1.w;
-	k2.t_offset = t_offset; k2.weight_batch = total_batch;
-	prof_begin(self, 1);
-	HIP_TRY(launch_k2(k2, 1, self->stream), "launch count");
-	prof_end(self);
+	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch))
+		return -EIO;
 
+	/* the ring advances with the data (host state), so the next frame can be accumulated
+	 * before this one is merged */
+	self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
 	self->acc_total = total_batch;
 	self->state = ST_PENDING;
 	return 0;
@@ -637,13 +688,21 @@ error:
 	return -EIO;
 }
 
+extern "C" int fosphor_amd_set_partial_slot(struct fosphor *self, int slot)
+{
+	if (!self || slot < 0 || slot >= self->max_batches)
+		return -EINVAL;
+	self->slot = slot;
+	return 0;
+}
+
 extern "C" int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd_partials *out)
 {
 	if (!self || !out)
 		return -EINVAL;
-	out->d_hc = self->d_hc;
-	out->d_live_sum = self->d_live_sum;
-	out->d_max = self->d_vmax;
+	out->d_hc = self->d_hc + (size_t)self->slot * self->n_bins * kN;
+	out->d_live_sum = self->d_live_sum + (size_t)self->slot * kN;
+	out->d_max = self->d_vmax + (size_t)self->slot * kN;
 	out->n_hc = self->n_bins * kN;
 	out->n_cols = kN;
 	return 0;
@@ -651,25 +710,16 @@ extern "C" int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd
 
 extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 {
-	K3Params k3;
 	if (!self || total_batch < 16)
 		return -EINVAL;
 	if (prepare(self))
 		return -EIO;
-	memset(&k3, 0, sizeof(k3));
-	k3.hc = self->d_hc; k3.live_sum = self->d_live_sum; k3.vmax = self->d_vmax;
-	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
-	k3.n_batches = 1; k3.batch = total_batch; k3.n_bins = self->n_bins;
-	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
-	prof_begin(self, 2);
-	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
-	prof_end(self);
-	self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
+	if (run_merge(self, 1, total_batch, self->slot))
+		return -EIO;
 	self->last_batches = 1;
+	self->last_slot0 = self->slot;
 	self->state = ST_PENDING;
 	return 0;
-error:
-	return -EIO;
 }
 
 /* ------------------------------------------------------------------------ */

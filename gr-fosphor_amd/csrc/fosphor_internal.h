@@ -45,20 +45,32 @@ struct K1Params {
 	float w;			/* 1 - alpha */
 };
 
-/* K2: bin indices -> hit counts + per-batch live sum / max per column */
+/* K2: bin indices -> hit counts + live sum / max per column.
+ * Grid (N/16 column slabs, chunks): a chunk is `chunk` consecutive spectra of one batch.
+ * chunks_per_batch == 1: counts are stored; otherwise they are added with integer atomics
+ * into hc[f] (zeroed by the host first) -- integer sums are order-independent, so the result
+ * is bit-identical either way.  Float partials go out per chunk and are reduced in a fixed
+ * order by k2b_reduce (deterministic). */
 struct K2Params {
 	const uint32_t *bins;		/* [total/4][N] */
 	const float2   *partial;	/* [total/tile][N] */
 	uint32_t *hc;			/* [n_batches][n_bins][N] */
-	float    *live_sum;		/* [n_batches][N] */
-	float    *vmax;			/* [n_batches][N] */
-	int   batch;			/* spectra per batch */
+	float    *chunk_sum;		/* [n_chunks][N] */
+	float    *chunk_max;		/* [n_chunks][N] */
+	int   batch;			/* spectra per batch in this launch */
+	int   chunk;			/* spectra per chunk; divides batch */
 	int   tile;
 	int   n_bins;
 	float w;
 	/* sharded batch (multi-GPU): this launch holds spectra [t_offset, t_offset+batch)
 	 * of a batch of weight_batch spectra; single GPU: t_offset 0, weight_batch = batch */
 	int   t_offset, weight_batch;
+};
+
+struct K2bParams {
+	const float *chunk_sum, *chunk_max;	/* [n_batches * cpb][N] */
+	float *live_sum, *vmax;			/* [n_batches][N] */
+	int   n_batches, cpb;
 };
 
 /* K3: histogram rise/decay, live EMA, max-hold */
@@ -73,7 +85,8 @@ struct K3Params {
 };
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
-hipError_t launch_k2(const K2Params &p, int n_batches, hipStream_t s);
+hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s);
+hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,

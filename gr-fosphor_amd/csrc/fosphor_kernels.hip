@@ -441,7 +441,10 @@ void k2_count(const K2Params p)
 	const int col  = tid & 15;
 	const int row  = tid >> 4;
 	const int x0   = blockIdx.x * 16;
-	const int f    = blockIdx.y;
+	const int c    = blockIdx.y;			/* chunk index within the launch */
+	const int cpb  = p.batch / p.chunk;		/* chunks per batch */
+	const int f    = c / cpb;			/* batch index */
+	const int t_in = (c - f * cpb) * p.chunk;	/* first spectrum of the chunk within its batch */
 	const int nb   = p.n_bins;
 
 	for (int i = tid; i < nb * 16; i += 256)
@@ -449,8 +452,8 @@ void k2_count(const K2Params p)
 	__syncthreads();
 
 	/* bins: one dword = 4 consecutive spectra of one column */
-	const uint32_t *src = p.bins + (size_t)f * (p.batch >> 2) * kN + x0 + col;
-	for (int q = row; q < (p.batch >> 2); q += 16) {
+	const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * kN + x0 + col;
+	for (int q = row; q < (p.chunk >> 2); q += 16) {
 		const uint32_t v = src[(size_t)q * kN];
 		atomicAdd(&h[((v      ) & 0xff) * 16 + col], 1u);
 		atomicAdd(&h[((v >>  8) & 0xff) * 16 + col], 1u);
@@ -461,12 +464,12 @@ void k2_count(const K2Params p)
 	/* live sum: sum_t pwr_t (1-a)^(B-1-t) from the tile partials, which hold
 	 * sum_{t in tile} pwr_t (1-a)^(t_last - t) (display.cl:149-150) */
 	{
-		const int tiles = p.batch / p.tile;
-		const float2 *pp = p.partial + (size_t)f * tiles * kN + x0 + col;
+		const int tiles = p.chunk / p.tile;
+		const float2 *pp = p.partial + (size_t)c * tiles * kN + x0 + col;
 		float s = 0.0f, m = -1000.0f;
 		for (int j = row; j < tiles; j += 16) {
 			const float2 v = pp[(size_t)j * kN];
-			const int t_last = p.t_offset + (j + 1) * p.tile - 1;
+			const int t_last = p.t_offset + t_in + (j + 1) * p.tile - 1;
 			s += v.x * powf(p.w, (float)(p.weight_batch - 1 - t_last));
 			m = (m < v.y) ? v.y : m;
 		}
@@ -481,18 +484,51 @@ void k2_count(const K2Params p)
 			s += red_s[j][tid];
 			m = (m < red_m[j][tid]) ? red_m[j][tid] : m;
 		}
-		p.live_sum[(size_t)f * kN + x0 + tid] = s;
-		p.vmax[(size_t)f * kN + x0 + tid] = m;
+		p.chunk_sum[(size_t)c * kN + x0 + tid] = s;
+		p.chunk_max[(size_t)c * kN + x0 + tid] = m;
 	}
 
 	uint32_t *dst = p.hc + (size_t)f * nb * kN + x0 + col;
-	for (int b = row; b < nb; b += 16)
-		dst[(size_t)b * kN] = h[b * 16 + col];
+	if (cpb == 1) {
+		for (int b = row; b < nb; b += 16)
+			dst[(size_t)b * kN] = h[b * 16 + col];
+	} else {
+		for (int b = row; b < nb; b += 16) {
+			const uint32_t v = h[b * 16 + col];
+			if (v)
+				atomicAdd(&dst[(size_t)b * kN], v);
+		}
+	}
 }
 
-hipError_t launch_k2(const K2Params &p, int n_batches, hipStream_t s)
+hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
-	hipLaunchKernelGGL(k2_count, dim3(kN / 16, n_batches), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k2_count, dim3(kN / 16, n_chunks), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+/* fixed-order reduction of the chunk partials of each batch */
+__global__ __launch_bounds__(256)
+void k2b_reduce(const K2bParams p)
+{
+	const int gid = blockIdx.x * 256 + threadIdx.x;
+	if (gid >= p.n_batches * kN)
+		return;
+	const int f = gid / kN, x = gid - f * kN;
+	float s = 0.0f, m = -1000.0f;
+	for (int c = 0; c < p.cpb; c++) {
+		const size_t i = (size_t)(f * p.cpb + c) * kN + x;
+		s += p.chunk_sum[i];
+		m = (m < p.chunk_max[i]) ? p.chunk_max[i] : m;
+	}
+	p.live_sum[gid] = s;
+	p.vmax[gid] = m;
+}
+
+hipError_t launch_k2b(const K2bParams &p, hipStream_t s)
+{
+	const int threads = p.n_batches * kN;
+	hipLaunchKernelGGL(k2b_reduce, dim3((threads + 255) / 256), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 

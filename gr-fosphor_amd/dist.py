@@ -32,20 +32,24 @@ def wrap_device_array(ptr, shape, dtype):
     return torch.as_tensor(_DeviceArray(ptr, shape, _TYPESTR[str(dtype)]), device="cuda")
 
 
-def allreduce_partials(hc, live_sum, vmax, group=None):
+def allreduce_partials(hc, live_sum, vmax, group=None, async_op=False):
     """The per-frame exchange.  Tensors are reduced in place; works on any backend
     (RCCL on GPU tensors, gloo on CPU tensors in the tests).  hc must be an integer tensor
-    (uint32 counts viewed as int32: sums stay below 2^31 for any batch < 2^31 spectra)."""
+    (uint32 counts viewed as int32: sums stay below 2^31 for any batch < 2^31 spectra).
+    async_op=True returns the work handles (wait() makes the current stream wait, not the host)."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return
+        return []
     works = [
         dist.all_reduce(hc, op=dist.ReduceOp.SUM, group=group, async_op=True),
         dist.all_reduce(live_sum, op=dist.ReduceOp.SUM, group=group, async_op=True),
         dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=group, async_op=True),
     ]
+    if async_op:
+        return works
     for w in works:
         w.wait()
+    return []
 
 
 def shard_range(total_batch, rank, world):
@@ -62,6 +66,10 @@ class ShardedFosphor:
     frame(d_samples_local, total_batch): K1+K2 on the local shard, all-reduce, K3.
     The semantics are one reference display launch with fft_batch = total_batch (the kernel
     is batch-generic; only the host caps it, cl.c:885).
+
+    With overlap=True the exchange of frame k is left in flight while the caller submits
+    frame k+1 (two partial-array slots in the library); its merge is queued behind frame k+1's
+    FFT.  Call flush() to retire the last frame.
     """
 
     def __init__(self, fosphor_cls, rank, world, group=None, **kw):
@@ -71,20 +79,44 @@ class ShardedFosphor:
         # run the library on torch's current stream so the collective is ordered after K2
         # and K3 after the collective without host synchronisation
         self.f = fosphor_cls(stream=torch.cuda.current_stream().cuda_stream, **kw)
-        p = self.f.partials()
-        self.hc = wrap_device_array(p.d_hc, (p.n_hc,), torch.int32)
-        self.live = wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32)
-        self.vmax = wrap_device_array(p.d_max, (p.n_cols,), torch.float32)
+        self.views = []
+        for slot in (0, 1):
+            self.f.set_partial_slot(slot)
+            p = self.f.partials()
+            self.views.append((wrap_device_array(p.d_hc, (p.n_hc,), torch.int32),
+                               wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32),
+                               wrap_device_array(p.d_max, (p.n_cols,), torch.float32)))
+        self.k = 0
+        self.pending = None		# (works, slot, total_batch)
 
-    def frame(self, d_samples_local, total_batch):
+    def _retire(self):
+        if self.pending is None:
+            return
+        works, slot, total = self.pending
+        for w in works:
+            w.wait()
+        self.f.set_partial_slot(slot)
+        rv = self.f.merge(total)
+        if rv:
+            raise RuntimeError("merge -> %d" % rv)
+        self.pending = None
+
+    def frame(self, d_samples_local, total_batch, overlap=False):
         off, n = shard_range(total_batch, self.rank, self.world)
+        slot = self.k & 1
+        self.k += 1
+        self.f.set_partial_slot(slot)
         rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)
         if rv:
             raise RuntimeError("accumulate_device -> %d" % rv)
-        allreduce_partials(self.hc, self.live, self.vmax, self.group)
-        rv = self.f.merge(total_batch)
-        if rv:
-            raise RuntimeError("merge -> %d" % rv)
+        works = allreduce_partials(*self.views[slot], group=self.group, async_op=True)
+        self._retire()			# previous frame: wait for ITS exchange, merge
+        self.pending = (works, slot, total_batch)
+        if not overlap:
+            self._retire()
+
+    def flush(self):
+        self._retire()
 
 
 def combine_partials_numpy(parts):

@@ -100,9 +100,14 @@ int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *
  * ranks in contiguous time blocks: this rank holds spectra
  * [t_offset, t_offset + n_local).  Runs K1+K2 and leaves the three partial
  * arrays in device memory; nothing persistent is updated except this rank's
- * waterfall rows. */
+ * waterfall rows and the ring position (advanced by total_batch). */
 int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
                                   int n_local, int t_offset, int total_batch);
+
+/* Select which of the instance's partial-array slots (0 .. max_batches-1) the next
+ * accumulate / get_partials / merge use.  Two slots let the all-reduce of frame k overlap the
+ * FFT of frame k+1. */
+int fosphor_amd_set_partial_slot(struct fosphor *self, int slot);
 
 /* The partial arrays to all-reduce: hc uint32[n_bins][N] (sum),
  * live_sum float[N] (sum), max float[N] (max). */
@@ -115,8 +120,7 @@ struct fosphor_amd_partials
 };
 int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd_partials *out);
 
-/* Apply K3 with the (reduced) partial arrays as one batch of total_batch
- * spectra, and advance the waterfall ring by total_batch. */
+/* Apply K3 with the (reduced) partial arrays as one batch of total_batch spectra. */
 int fosphor_amd_merge(struct fosphor *self, int total_batch);
 
 /* ---- measurement ---------------------------------------------------------- */
