@@ -6,7 +6,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libfosphor_amd.so")
+# FOSPHOR_AMD_LIB lets the tuning harness (tools/ab_bench.sh) point at an alternative build
+LIB_PATH = os.environ.get("FOSPHOR_AMD_LIB") or os.path.join(PKG_DIR, "libfosphor_amd.so")
 
 
 class Config(C.Structure):

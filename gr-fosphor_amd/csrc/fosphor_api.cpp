@@ -35,6 +35,8 @@ using namespace fosphor_amd;
 
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
+static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
+
 struct fosphor
 {
 	/* geometry / constants */
@@ -64,6 +66,10 @@ struct fosphor
 	uint32_t *d_hc;
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
+	float2   *d_rise;			/* [kRiseMax+1] (d, e) per hit count */
+	float2   *h_rise;			/* pinned */
+	int       rise_batch;			/* batch the table was built for (0 = none) */
+	float     rise_t0r, rise_t0d;
 	int       slot;				/* partial-array slot used by accumulate/merge */
 	float2   *d_fft_tmp;			/* fosphor_amd_fft scratch is caller-provided; unused */
 
@@ -162,6 +168,8 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_bins); (void)hipFree(self->d_partial); (void)hipFree(self->d_hc);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
+	(void)hipFree(self->d_rise);
+	if (self->h_rise) (void)hipHostFree(self->h_rise);
 	for (int i = 0; i < 2; i++) {
 		if (self->h_stage[i]) (void)hipHostFree(self->h_stage[i]);
 		if (self->d_stage[i]) (void)hipFree(self->d_stage[i]);
@@ -249,6 +257,8 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
 	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk sums");
 	HIP_TRY(hipMalloc((void **)&self->d_chunk_max, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk max");
+	HIP_TRY(hipMalloc((void **)&self->d_rise, sizeof(float2) * (kRiseMax + 1)), "alloc rise table");
+	HIP_TRY(hipHostMalloc((void **)&self->h_rise, sizeof(float2) * (kRiseMax + 1), hipHostMallocDefault), "alloc pinned rise table");
 	HIP_TRY(hipHostMalloc((void **)&self->h_thr, sizeof(double) * (self->n_bins + 1), hipHostMallocDefault), "alloc pinned thr");
 	HIP_TRY(hipHostMalloc((void **)&self->h_win, sizeof(float) * kN, hipHostMallocDefault), "alloc pinned win");
 
@@ -450,11 +460,39 @@ error:
 	return -EIO;
 }
 
+/* (d, e) of display.cl:241-245 for every possible hit count of a batch.  Same float
+ * expressions as the kernel source, powf from the host libm (the oracle's binding). */
+static int ensure_rise_table(struct fosphor *self, int batch)
+{
+	if (batch > kRiseMax)
+		return 0;
+	if (self->rise_batch == batch && self->rise_t0r == self->t0r && self->rise_t0d == self->t0d)
+		return 1;
+	(void)hipStreamSynchronize(self->stream);	/* h_rise may be in flight */
+	for (int hc = 0; hc <= batch; hc++) {
+		const float a = (float)hc / (float)batch;
+		const float b = a * (1.0f / self->t0r);
+		const float c = b + (1.0f / self->t0d);
+		const float d = b * (1.0f / c);
+		const float e = powf(1.0f - c, (float)batch);
+		self->h_rise[hc] = make_float2(d, e);
+	}
+	if (hipMemcpyAsync(self->d_rise, self->h_rise, sizeof(float2) * (batch + 1), hipMemcpyHostToDevice, self->stream) != hipSuccess)
+		return -1;
+	self->rise_batch = batch; self->rise_t0r = self->t0r; self->rise_t0d = self->t0d;
+	return 1;
+}
+
 static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0)
 {
 	K3Params k3;
 	const size_t cells = (size_t)self->n_bins * kN;
+	const int have_table = ensure_rise_table(self, batch);
+	if (have_table < 0)
+		return -EIO;
 	memset(&k3, 0, sizeof(k3));
+	k3.rise = have_table ? self->d_rise : NULL;
+	k3.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
 	k3.hc = self->d_hc + (size_t)slot0 * cells;
 	k3.live_sum = self->d_live_sum + (size_t)slot0 * kN;
 	k3.vmax = self->d_vmax + (size_t)slot0 * kN;

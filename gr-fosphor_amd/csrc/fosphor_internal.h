@@ -80,8 +80,10 @@ struct K3Params {
 	const float    *vmax;		/* [n_batches][N] */
 	float  *hist;			/* [n_bins][N] */
 	float2 *spectrum;		/* [2][N] */
+	const float2 *rise;		/* [batch+1] (d, e) per hit count, or nullptr -> computed in-kernel */
 	int   n_batches, batch, n_bins;
 	float t0r, t0d, alpha;
+	float live_decay;		/* (1-alpha)^batch */
 };
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s);

@@ -149,20 +149,31 @@ static __device__ __forceinline__ int bin_fast(float re, float im, const BinCons
 	const float l2 = __builtin_amdgcn_logf(s);		/* v_log_f32 */
 	const float v  = __builtin_fmaf(k.A, l2, k.C);
 	const float r  = __builtin_rintf(v);
-	const float d  = __builtin_fabsf(v - r);
-	/* clamp in float first (fmax(NaN, 0) = 0), so the conversion is always defined */
-	const int g = (int)__builtin_fminf(__builtin_fmaxf(r, 0.0f), (float)(k.nb - 1));
+	/* clamp in float first (med3; NaN -> 0), so the conversion is always defined */
+	const int g = (int)__builtin_amdgcn_fmed3f(r, 0.0f, (float)(k.nb - 1));
 	*pwr = l2 * F_HALF_LOG10_2;
-	/* confident: well inside a bin, and |X|^2 in the range where v_log_f32's error bound
-	 * used to size `amb` holds.  Values that clamp (far below bin 0 / above the top bin)
-	 * are also confident: d is irrelevant there, but keeping one rule costs nothing. */
-	*ok = (d <= k.amb) & (s >= 2.3283064e-10f) & (s <= 4.2949673e9f);
+	/* confident: well inside a bin, and |X|^2 within [2^-32, 2^32) where the v_log_f32 error
+	 * bound used to size `amb` holds -- one unsigned compare on the exponent field:
+	 * bits(2^-32) = 0x2f800000, bits(2^32) = 0x4f800000.  NaN / inf / 0 / negative fail it. */
+	const unsigned su = __float_as_uint(s);
+	*ok = (__builtin_fabsf(v - r) <= k.amb) & ((su - 0x2f800000u) < 0x20000000u);
 	return g;
 }
 
 /* ------------------------------------------------------------------------ */
 /* K1                                                                       */
 /* ------------------------------------------------------------------------ */
+
+/* Tunables (tools/ab_bench.sh builds variants with -D...) */
+#ifndef K1_WAVES_PER_SIMD
+#define K1_WAVES_PER_SIMD 2		/* __launch_bounds__ second argument */
+#endif
+#ifndef K1_PREFETCH
+#define K1_PREFETCH 1			/* register prefetch of the next spectrum */
+#endif
+#ifndef K1_TW3_LDS
+#define K1_TW3_LDS 0			/* pass-3 twiddles from an LDS table instead of registers */
+#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -177,35 +188,49 @@ static __device__ __forceinline__ void load_iq16(float2 (&x)[16], const float2 *
 }
 
 template <bool WRITE_FFT>
-__global__ __launch_bounds__(256, 2)
+__global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
 void k1_fft_bin(const K1Params p)
 {
-	__shared__ float2 lds[4][kN];			/* 8 KiB per wave */
+	__shared__ float2 lds[4][kN];			/* 8 KiB exchange slab per wave */
+	__shared__ float2 tw4_tab[512];			/* pass-4 twiddles, shared by the block */
+	__shared__ float  win_tab[kN];			/* window, shared by the block */
+#if K1_TW3_LDS
+	__shared__ float2 tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
+#endif
 
 	const int lane   = threadIdx.x & 63;
 	const int wv     = threadIdx.x >> 6;
 	const int ntiles = p.total / p.tile;
 	const int stride = gridDim.x * 4;		/* waves in the grid */
 	int tile = blockIdx.x * 4 + wv;
+
+	for (int i = threadIdx.x; i < kN; i += 256)
+		win_tab[i] = p.win[i];
+	for (int i = threadIdx.x; i < 512; i += 256)
+		tw4_tab[i] = p.tw[kTw4Off + i];
+#if K1_TW3_LDS
+	for (int i = threadIdx.x; i < 7 * 64; i += 256)
+		tw3_tab[i % 7][i / 7] = p.tw[kTw3Off + i];
+#endif
+	__syncthreads();				/* the only block-wide barrier */
+
 	if (tile >= ntiles)
-		return;					/* whole wave leaves; no block-wide barrier is used */
+		return;					/* whole wave leaves */
 
 	float2 *buf = lds[wv];
 
 	/* ---- per-lane constants, loaded once per tile ------------------------- */
-	float  win[16];
-	float2 tw2[7], tw3[7], tw4[8];
-#pragma unroll
-	for (int m = 0; m < 16; m++)
-		win[m] = p.win[lane + 64 * m];
+	float2 tw2[7];
+#if !K1_TW3_LDS
+	float2 tw3[7];
+#endif
 #pragma unroll
 	for (int n = 0; n < 7; n++) {
 		tw2[n] = p.tw[kTw2Off + (lane & 7) * 7 + n];	/* k = i & 7  (both virtual items) */
+#if !K1_TW3_LDS
 		tw3[n] = p.tw[kTw3Off + lane * 7 + n];		/* k = i & 63 = lane               */
+#endif
 	}
-#pragma unroll
-	for (int c = 0; c < 8; c++)
-		tw4[c] = p.tw[kTw4Off + lane + 64 * c];		/* k = lane + 64c                  */
 
 	/* ---- swizzled LDS addressing -------------------------------------------
 	 * element e lives at phys(e) = e ^ ((e >> 3) & 15): every access below is
@@ -220,7 +245,9 @@ void k1_fft_bin(const K1Params p)
 	const BinConst bk = { p.binA, p.binC, p.amb, p.n_bins, p.thr };
 
 	float2 xn[16];
+#if K1_PREFETCH
 	load_iq16(xn, p.iq + (size_t)tile * p.tile * kN + lane);
+#endif
 
 	/* persistent wave: tiles tile, tile + stride, ... (per-lane constants stay in registers) */
 	for (; tile < ntiles; tile += stride) {
@@ -244,11 +271,18 @@ void k1_fft_bin(const K1Params p)
 			const int t = t0 + g0 + u;
 			float2 x[16];
 
+#if !K1_PREFETCH
+			load_iq16(xn, p.iq + (size_t)t * kN + lane);
+#endif
 			/* window (fft.cl:415-417) */
 #pragma unroll
 			for (int m = 0; m < 16; m++)
-				x[m] = make_float2(xn[m].x * win[m], xn[m].y * win[m]);
+			{
+				const float w = win_tab[lane + 64 * m];
+				x[m] = make_float2(xn[m].x * w, xn[m].y * w);
+			}
 
+#if K1_PREFETCH
 			/* prefetch the next spectrum this wave will process */
 			{
 				const bool last = (g0 + u + 1 == p.tile);
@@ -256,6 +290,7 @@ void k1_fft_bin(const K1Params p)
 				if (!last || tile + stride < ntiles)
 					load_iq16(xn, p.iq + (size_t)t_next * kN + lane);
 			}
+#endif
 
 			/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) --------
 			 * virtual work-item i = lane + 64v owns elements i + 128j = lane + 64(v + 2j) */
@@ -302,7 +337,11 @@ void k1_fft_bin(const K1Params p)
 				r[0] = x[v];
 #pragma unroll
 				for (int j = 1; j < 8; j++)
+#if K1_TW3_LDS
+					r[j] = c_mul(x[v + 2 * j], tw3_tab[j - 1][lane]);
+#else
 					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
+#endif
 				dft8(r);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)	/* e = 512v + lane + 64jj */
@@ -320,7 +359,7 @@ void k1_fft_bin(const K1Params p)
 #pragma unroll
 			for (int c = 0; c < 8; c++) {
 				float2 a = x[c];
-				float2 b = c_mul(x[c + 8], tw4[c]);
+				float2 b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);	/* k = lane + 64c */
 				DFT2(a, b);
 				x[c] = a;
 				x[c + 8] = b;
@@ -366,8 +405,8 @@ void k1_fft_bin(const K1Params p)
 				for (int q = 0; q < 4; q++) {
 					const int m = m0 + q;
 					pack[m] |= bn[q] << (8 * u);
-					live[m] = live[m] * p.w + pw[q];			/* Horner form of display.cl:149-150 */
-					vmax[m] = (vmax[m] < pw[q]) ? pw[q] : vmax[m];		/* OpenCL max(), display.cl:139 */
+					live[m] = __builtin_fmaf(live[m], p.w, pw[q]);		/* Horner form of display.cl:149-150 (tolerance-checked float) */
+					vmax[m] = __builtin_fmaxf(vmax[m], pw[q]);		/* = OpenCL max() here: NaN pwr is ignored, display.cl:139 */
 					if (store_row)
 						wf_row[64 * m] = pw[q];				/* display.cl:142-146 */
 				}
@@ -453,7 +492,22 @@ void k2_count(const K2Params p)
 
 	/* bins: one dword = 4 consecutive spectra of one column */
 	const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * kN + x0 + col;
-	for (int q = row; q < (p.chunk >> 2); q += 16) {
+	const int nq = p.chunk >> 2;
+	int q = row;
+	for (; q + 48 < nq; q += 64) {			/* 4 independent loads in flight per thread */
+		uint32_t v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			v[u] = src[(size_t)(q + 16 * u) * kN];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			atomicAdd(&h[((v[u]      ) & 0xff) * 16 + col], 1u);
+			atomicAdd(&h[((v[u] >>  8) & 0xff) * 16 + col], 1u);
+			atomicAdd(&h[((v[u] >> 16) & 0xff) * 16 + col], 1u);
+			atomicAdd(&h[((v[u] >> 24)       ) * 16 + col], 1u);
+		}
+	}
+	for (; q < nq; q += 16) {
 		const uint32_t v = src[(size_t)q * kN];
 		atomicAdd(&h[((v      ) & 0xff) * 16 + col], 1u);
 		atomicAdd(&h[((v >>  8) & 0xff) * 16 + col], 1u);
@@ -544,21 +598,54 @@ void k3_merge(const K3Params p)
 	const float fbatch = (float)p.batch;
 
 	if (gid < cells) {
-		/* one (bin, x) cell; batches applied in order (display.cl:217-254) */
+		/* one (bin, x) cell; batches applied in order (display.cl:217-254).
+		 * d and e of display.cl:241-245 depend only on the hit count: with a table
+		 * rise[hc] = (d, e) (host-computed with the same powf the oracle uses) the update
+		 * is a lookup and display.cl:247,250. */
 		float hv = p.hist[gid];
-		const float rt0r = 1.0f / p.t0r, rt0d = 1.0f / p.t0d;
-		for (int f = 0; f < p.n_batches; f++) {
-			const uint32_t hc = p.hc[(size_t)f * cells + gid];
-			if ((hv <= 0.01f) && (hc == 0))			/* display.cl:237-238 */
-				continue;
-			const float a = (float)hc / fbatch;		/* display.cl:241-245 */
-			const float b = a * rt0r;
-			const float c = b + rt0d;
-			const float d = b * (1.0f / c);
-			const float e = powf(1.0f - c, fbatch);
-			hv = (hv - d) * e + d;				/* display.cl:247 */
-			hv = (hv < 0.0f) ? 0.0f : hv;			/* clamp, display.cl:250 */
-			hv = (1.0f < hv) ? 1.0f : hv;
+		if (p.rise) {
+			/* 8 batches of counts in flight per thread: the loop is otherwise one dependent
+			 * HBM/L2 round trip per batch */
+			int f = 0;
+			for (; f + 8 <= p.n_batches; f += 8) {
+				uint32_t hc[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					hc[u] = __builtin_nontemporal_load(&p.hc[(size_t)(f + u) * cells + gid]);
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
+						const float2 de = p.rise[hc[u]];
+						hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
+						hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
+						hv = (1.0f < hv) ? 1.0f : hv;
+					}
+				}
+			}
+			for (; f < p.n_batches; f++) {
+				const uint32_t hc = p.hc[(size_t)f * cells + gid];
+				if (!((hv <= 0.01f) && (hc == 0))) {
+					const float2 de = p.rise[hc];
+					hv = (hv - de.x) * de.y + de.x;
+					hv = (hv < 0.0f) ? 0.0f : hv;
+					hv = (1.0f < hv) ? 1.0f : hv;
+				}
+			}
+		} else {
+			const float rt0r = 1.0f / p.t0r, rt0d = 1.0f / p.t0d;
+			for (int f = 0; f < p.n_batches; f++) {
+				const uint32_t hc = p.hc[(size_t)f * cells + gid];
+				if ((hv <= 0.01f) && (hc == 0))			/* display.cl:237-238 */
+					continue;
+				const float a = (float)hc / fbatch;		/* display.cl:241-245 */
+				const float b = a * rt0r;
+				const float c = b + rt0d;
+				const float d = b * (1.0f / c);
+				const float e = powf(1.0f - c, fbatch);
+				hv = (hv - d) * e + d;				/* display.cl:247 */
+				hv = (hv < 0.0f) ? 0.0f : hv;			/* clamp, display.cl:250 */
+				hv = (1.0f < hv) ? 1.0f : hv;
+			}
 		}
 		p.hist[gid] = hv;
 	} else if (gid < cells + kN) {
@@ -566,8 +653,7 @@ void k3_merge(const K3Params p)
 		const int x = gid - cells;
 		const int half = kN >> 1;
 		const int i = x ^ half;
-		const float oma = 1.0f - p.alpha;
-		const float decay = powf(oma, fbatch);
+		const float decay = p.live_decay;
 		float live = p.spectrum[i].y;
 		float mh   = p.spectrum[kN + i].y;
 		for (int f = 0; f < p.n_batches; f++) {
