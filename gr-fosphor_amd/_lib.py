@@ -81,6 +81,9 @@ SIGNATURES = {
     "fosphor_amd_merge": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_profile": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]),
+    "fosphor_amd_host_thresholds": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "fosphor_amd_host_twiddle_count": (C.c_int, []),
+    "fosphor_amd_host_twiddles": (C.c_int, [C.c_void_p]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
 }

@@ -803,3 +803,25 @@ extern "C" void fosphor_amd_priv_ranges(struct fosphor *self, int *db_ref, int *
 	*center = self->frequency.center;
 	*span = self->frequency.span;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Host-side tables (no GPU)                                                */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int fosphor_amd_host_thresholds(int n_bins, float histo_scale, float histo_offset, double *out)
+{
+	if (!out || n_bins < 2 || n_bins > 65536)
+		return -EINVAL;
+	build_thresholds(out, n_bins, histo_scale, histo_offset);
+	return 0;
+}
+
+extern "C" int fosphor_amd_host_twiddle_count(void) { return kTwLen; }
+
+extern "C" int fosphor_amd_host_twiddles(float *out)
+{
+	if (!out)
+		return -EINVAL;
+	build_twiddles((float2 *)out);
+	return 0;
+}

@@ -131,6 +131,20 @@ int fosphor_amd_merge(struct fosphor *self, int total_batch);
 void fosphor_amd_profile(struct fosphor *self, int enable);
 int  fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3]);
 
+/* ---- host-side tables (no GPU needed; exported for tests and for front ends) ---- */
+
+/* The exact bin thresholds the kernels compare |X|^2 against: out[n_bins + 1] doubles.
+ * out[b] (1 <= b < n_bins) = smallest s with bin(s) >= b under the pinned pipeline
+ * log10(hypot()) -> round(scale * (pwr + offset)) of display.cl:136,161-168;
+ * out[0] = -1; out[n_bins] = smallest s whose float hypot overflows. */
+int fosphor_amd_host_thresholds(int n_bins, float histo_scale, float histo_offset, double *out);
+
+/* The FFT twiddle table the kernels use (fft.cl:62-68,162-166,286-297 with the pinned
+ * sin/cos): out[2 * fosphor_amd_host_twiddle_count()] floats, (cos, sin) pairs laid out
+ * pass 2 [k<8][n=1..7], pass 3 [k<64][n=1..7], pass 4 [k<512]. */
+int fosphor_amd_host_twiddle_count(void);
+int fosphor_amd_host_twiddles(float *out);
+
 /* hipStream_t the instance runs on. */
 void *fosphor_amd_stream(struct fosphor *self);
 

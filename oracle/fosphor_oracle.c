@@ -300,6 +300,17 @@ int fosphor_oracle_bin(float re, float im, float hs, float ho, int n_bins)
 	return fpm_bin_from_pwr(pwr, hs, ho, n_bins);	/* display.cl:161-168 */
 }
 
+/* The twiddle factor the restatement multiplies by, for table checks:
+ * radix 8 (fft.cl:285-297): alpha = -pi*k/(4p), factor n; radix 2 (fft.cl:161-167): radix2 != 0,
+ * alpha = -pi*k/p, n = 1. */
+void fosphor_oracle_twiddle(int radix2, int p, int k, int n, float *cs)
+{
+	float alpha = radix2 ? (-ORACLE_PI_F * (float)k / (float)(p))
+	                     : (-ORACLE_PI_F * (float)k / (float)(4 * p));
+	cs[0] = fpm_cosf((float)n * alpha);
+	cs[1] = fpm_sinf((float)n * alpha);
+}
+
 /* Vectorised form for kernel-level tests: bin index and log-power of n FFT outputs */
 void fosphor_oracle_bins(const float *fft, int n, float hs, float ho, int n_bins, int32_t *bin, float *pwr)
 {

@@ -60,6 +60,7 @@ void fosphor_oracle_fft(int fft_len_log, const float *in, float *out,
                         const float *win, int n_spectra);
 /* bin index of one FFT output sample, display.cl:136,161-168 */
 int  fosphor_oracle_bin(float re, float im, float histo_scale, float histo_ofs, int n_bins);
+void fosphor_oracle_twiddle(int radix2, int p, int k, int n, float *cs);
 void fosphor_oracle_bins(const float *fft, int n, float histo_scale, float histo_ofs, int n_bins,
                          int32_t *bin, float *pwr);
 

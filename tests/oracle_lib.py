@@ -61,6 +61,7 @@ class Oracle:
             L.fosphor_oracle_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
             L.fosphor_oracle_fft.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             L.fosphor_oracle_bin.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]
+            L.fosphor_oracle_twiddle.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
             L.fosphor_oracle_bins.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
             for n in ("waterfall", "histogram", "spectrum", "fft_out"):
                 f = getattr(L, "fosphor_oracle_" + n)

@@ -1,0 +1,154 @@
+"""CPU: the drop-in boundary without a GPU -- the C-ABI library loads, exports every symbol the
+headers declare, refuses to run without a device (no CPU fallback), and its host-side tables
+(bin thresholds, twiddles) agree with the oracle.  No compute kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, oracle_bins
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from _pkg import gr_fosphor_amd
+    if not os.path.exists(gr_fosphor_amd.LIB_PATH):
+        gr_fosphor_amd.build()		# hipcc cross-compiles gfx950 without a GPU
+    gr_fosphor_amd.load()
+    return gr_fosphor_amd
+
+
+def declared_functions(header):
+    """function names declared in a header (crude but sufficient for these plain-C headers)"""
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(fosphor_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(amd):
+    lib = C.CDLL(amd.LIB_PATH)
+    want = declared_functions("fosphor.h") + declared_functions("fosphor_amd.h")
+    assert "fosphor_process" in want and "fosphor_amd_process_device" in want and len(want) >= 30
+    missing = [n for n in want if not hasattr(lib, n)]
+    assert not missing, "declared but not exported: %s" % missing
+    # and the ctypes binding covers them all
+    from gr_fosphor_amd import _lib
+    unbound = [n for n in want if n not in _lib.SIGNATURES]
+    assert not unbound, "exported but unbound in _lib.py: %s" % unbound
+
+
+def test_struct_layouts_match_reference_abi(amd):
+    """struct fosphor_render / fosphor_channel layout (fosphor.h:42-90 of the reference):
+    10 user words, 8 channels of 3 words, then 11 private words."""
+    assert C.sizeof(amd.Render) == 4 * (10 + 8 * 3 + 11)
+    assert amd.Render.channels.offset == 40
+    assert amd.Render._wf_pos.offset == 40 + 96
+    assert amd.Render._y_label.offset == C.sizeof(amd.Render) - 4
+
+
+def test_no_device_no_fallback(amd, capfd):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = amd.load()
+    assert L.fosphor_init() is None			# NULL, like the reference on failure (fosphor.c:70-73)
+    err = capfd.readouterr().err
+    assert "no CPU path" in err or "no HIP device" in err
+    with pytest.raises(RuntimeError):
+        amd.Fosphor()
+
+
+def test_render_geometry_helpers(amd):
+    """fosphor_render_defaults / refresh / pos mapping are pure CPU maths (fosphor.c:162-387)."""
+    L = amd.load()
+    r = amd.Render()
+    L.fosphor_render_defaults(C.byref(r))
+    assert (r.width, r.height, r.freq_n_div) == (1024, 1024, 10)
+    assert r.options == 0x17f and abs(r.histo_wf_ratio - 0.5) < 1e-9
+    L.fosphor_render_refresh(C.byref(r))
+    # width 1024: reserved 10+30 left, 10+10 right -> 964 usable -> 10 divisions of 96 px, 4 px slack
+    assert r.freq_n_div == 10 and r._x_div == 96.0
+    assert r._x[0] == 40.0 + 2.0 and r._x[1] == r._x[0] + 960.0 + 1.0
+    # height 1024 with waterfall + freq labels: (1024 - 40) * 0.5 = 492 -> 49 px divisions
+    assert r._y_histo_div == 49.0
+    assert r._y_histo[1] == 1014.0 and r._y_histo[0] == 1014.0 - 490.0 - 1.0
+    assert r._y_wf[0] == 10.0 and r._y_wf[1] == r._y_histo[0] - 10.0 - 10.0
+    inside = L.fosphor_render_pos_inside(C.byref(r), 500, 800)
+    assert inside == 3
+    assert L.fosphor_render_pos_inside(C.byref(r), 500, 100) == 5
+    assert L.fosphor_render_pos_inside(C.byref(r), 5, 5) == 0
+
+
+def test_bin_thresholds_reproduce_oracle_bins(amd, oracle_built):
+    """The table the GPU compares against must reproduce the oracle's
+    log10(hypot()) -> round() pipeline for any sample: count(s >= thr[b]) == oracle bin."""
+    L = amd.load()
+    rng = np.random.default_rng(3)
+    for n_bins, (db_ref, db_div) in [(128, (0, 10)), (256, (0, 10)), (128, (-20, 5)), (256, (10, 2))]:
+        o = Oracle(n_bins=n_bins)
+        o.set_power_range(db_ref, db_div)
+        thr = np.empty(n_bins + 1, np.float64)
+        assert L.fosphor_amd_host_thresholds(n_bins, o.histo_scale, o.histo_offset, thr.ctypes.data) == 0
+        assert thr[0] == -1.0 and np.all(np.diff(thr[1:]) >= 0)
+        # random samples + samples straddling every threshold by one ulp of the double
+        mag = np.exp(rng.uniform(np.log(1e-12), np.log(1e12), 200000))
+        ph = rng.uniform(0, 2 * np.pi, mag.size)
+        v = np.stack([mag * np.cos(ph), mag * np.sin(ph)], 1).astype(np.float32)
+        want, _ = oracle_bins(v, o.histo_scale, o.histo_offset, n_bins)
+        s = v[:, 0].astype(np.float64) ** 2 + v[:, 1].astype(np.float64) ** 2
+        got = np.searchsorted(thr[1:n_bins], s, side="right")
+        got = np.where(s >= thr[n_bins], 0, got)
+        assert np.array_equal(got, want)
+        # exactly at / just below each threshold, with (re, im) = (sqrt-free) axis samples:
+        # h = float; s = h*h exactly in double
+        for b in range(1, n_bins):
+            if thr[b] >= thr[n_bins]:
+                continue
+            h = np.float32(np.sqrt(thr[b]))
+            cand = np.array([np.nextafter(h, np.float32(0)), h, np.nextafter(h, np.float32(np.inf))], np.float32)
+            vv = np.stack([cand, np.zeros(3, np.float32)], 1)
+            w, _ = oracle_bins(vv, o.histo_scale, o.histo_offset, n_bins)
+            ss = cand.astype(np.float64) ** 2
+            g = np.searchsorted(thr[1:n_bins], ss, side="right")
+            assert np.array_equal(g, w), (n_bins, b)
+
+
+def test_twiddle_table_matches_oracle(amd, oracle_built):
+    L = amd.load()
+    OL = Oracle.lib()
+    n = L.fosphor_amd_host_twiddle_count()
+    assert n == 8 * 7 + 64 * 7 + 512
+    tw = np.empty((n, 2), np.float32)
+    assert L.fosphor_amd_host_twiddles(tw.ctypes.data) == 0
+    cs = np.empty(2, np.float32)
+    i = 0
+    for p in (8, 64):
+        for k in range(p):
+            for f in range(1, 8):
+                OL.fosphor_oracle_twiddle(0, p, k, f, cs.ctypes.data)
+                assert np.array_equal(tw[i].view(np.uint32), cs.view(np.uint32)), (p, k, f)
+                i += 1
+    for k in range(512):
+        OL.fosphor_oracle_twiddle(1, 512, k, 1, cs.ctypes.data)
+        assert np.array_equal(tw[i].view(np.uint32), cs.view(np.uint32)), k
+        i += 1
+    assert i == n
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not import, link or open anything under oracle/ (only tests,
+    smoke() and bench's cpu_baseline may)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "gr-fosphor_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(base, fn)).read()
+                if re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle_lib|from\s+oracle_lib|'
+                             r'libfosphor_oracle|libfosphor_ref|fosphor_oracle_[a-z]+\s*\(', txt):
+                    bad.append(os.path.join(base, fn))
+    assert not bad, bad

@@ -1,0 +1,92 @@
+"""CPU, world_size 2, gloo: the per-frame exchange of the multi-GPU path.
+
+Each rank holds the partial arrays of its time-shard of one batch (here produced by the CPU
+oracle, since there is no GPU): integer hit counts, weighted live sum, max.  After
+gr_fosphor_amd.dist.allreduce_partials every rank must hold exactly the counts of the whole
+batch (bit-exact: integer sums are order-independent), the same max, and the live sum within
+float tolerance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["FOSPHOR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FOSPHOR_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from _pkg import gr_fosphor_amd
+from gr_fosphor_amd.dist import allreduce_partials, shard_range, combine_partials_numpy
+from oracle_lib import Oracle, gaussian_iq, add_tone
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+B, N, alpha = 64, 1024, 0.002
+x = add_tone(gaussian_iq(B * N, 99), 0.2, 0.17)
+
+def partials(samples, t_off, total):
+    o = Oracle()
+    assert o.process(samples) == 0
+    n = samples.shape[0] // N
+    rows = o.waterfall[:n].astype(np.float64)
+    w = (1.0 - np.float32(alpha)).astype(np.float64) ** (total - 1 - (t_off + np.arange(n)))
+    return o.hitcount.T.copy(), (rows * w[:, None]).sum(0).astype(np.float32), rows.max(0).astype(np.float32)
+
+off, n = shard_range(B, rank, world)
+hc, live, vmax = partials(x[off * N:(off + n) * N], off, B)
+t_hc = torch.from_numpy(hc.astype(np.int32).reshape(-1))
+t_live = torch.from_numpy(live.copy()); t_max = torch.from_numpy(vmax.copy())
+allreduce_partials(t_hc, t_live, t_max)
+
+hc_f, live_f, max_f = partials(x, 0, B)
+assert np.array_equal(t_hc.numpy().reshape(hc_f.shape).astype(np.uint32), hc_f), "counts not bit-exact"
+assert int(t_hc.sum()) == B * N
+assert np.array_equal(t_max.numpy(), max_f), "max differs"
+assert np.allclose(t_live.numpy(), live_f, rtol=1e-5, atol=1e-6), "live sum differs"
+
+# the host combination rule agrees too
+parts = [partials(x[o_ * N:(o_ + n_) * N], o_, B) for o_, n_ in (shard_range(B, r, world) for r in range(world))]
+c_hc, c_live, c_max = combine_partials_numpy(parts)
+assert np.array_equal(c_hc, hc_f) and np.array_equal(c_max, max_f)
+
+# async form returns handles and leaves the same result
+t2 = torch.from_numpy(hc.astype(np.int32).reshape(-1)); l2 = torch.from_numpy(live.copy()); m2 = torch.from_numpy(vmax.copy())
+for wk in allreduce_partials(t2, l2, m2, async_op=True):
+    wk.wait()
+assert torch.equal(t2, t_hc) and torch.equal(m2, t_max)
+try:
+    shard_range(48, 0, 2 if world == 2 else world)   # 48 / 2 = 24: not a whole number of 16-spectrum groups
+    raise SystemExit("shard_range accepted a ragged split")
+except ValueError:
+    pass
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+def test_allreduce_partials_world2_gloo(oracle_built, tmp_path):
+    from _pkg import gr_fosphor_amd
+    if not os.path.exists(gr_fosphor_amd.LIB_PATH):
+        gr_fosphor_amd.build()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617",
+               WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+        assert "rank %d ok" % r in out
