@@ -61,8 +61,16 @@ struct fosphor
 	double   *d_thr;
 	float    *d_wf, *d_hist;
 	float2   *d_spectrum;
-	uint32_t *d_bins;
+	uint32_t *d_bins_pp[2];			/* ping-pong: K1 of launch i+1 overlaps K2/K3 of launch i */
+	float2   *d_partial_pp[2];
+	uint32_t *d_bins;			/* current set */
 	float2   *d_partial;
+	int       pp;
+	hipStream_t stream2;			/* K2/K3 of the multi-batch path */
+	hipEvent_t ev_k1_done[2];		/* K1 wrote set pp */
+	hipEvent_t ev_set_free[2];		/* K2 finished reading set pp */
+	int       set_used[2];
+	int       overlap;			/* 1: two-stream pipeline for process paths */
 	uint32_t *d_hc;
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
@@ -165,7 +173,13 @@ extern "C" void fosphor_release(struct fosphor *self)
 		(void)hipStreamSynchronize(self->stream);
 	(void)hipFree(self->d_win); (void)hipFree(self->d_tw); (void)hipFree(self->d_thr);
 	(void)hipFree(self->d_wf); (void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
-	(void)hipFree(self->d_bins); (void)hipFree(self->d_partial); (void)hipFree(self->d_hc);
+	for (int i = 0; i < 2; i++) {
+		(void)hipFree(self->d_bins_pp[i]); (void)hipFree(self->d_partial_pp[i]);
+		if (self->ev_k1_done[i]) (void)hipEventDestroy(self->ev_k1_done[i]);
+		if (self->ev_set_free[i]) (void)hipEventDestroy(self->ev_set_free[i]);
+	}
+	if (self->stream2) { (void)hipStreamSynchronize(self->stream2); (void)hipStreamDestroy(self->stream2); }
+	(void)hipFree(self->d_hc);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -250,8 +264,19 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * kN), "alloc waterfall");
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * kN), "alloc histogram");
 	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * kN), "alloc spectrum");
-	HIP_TRY(hipMalloc((void **)&self->d_bins, (size_t)self->max_spectra * kN), "alloc bin indices");
-	HIP_TRY(hipMalloc((void **)&self->d_partial, sizeof(float2) * tiles_max * kN), "alloc partials");
+	for (int i = 0; i < 2; i++) {
+		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * kN), "alloc bin indices");
+		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * kN), "alloc partials");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], hipEventDisableTiming), "create event");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_set_free[i], hipEventDisableTiming), "create event");
+	}
+	self->d_bins = self->d_bins_pp[0];
+	self->d_partial = self->d_partial_pp[0];
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	{
+		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
+		self->overlap = !(e && *e == '0');
+	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
 	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
@@ -332,7 +357,7 @@ extern "C" void fosphor_set_frequency_range(struct fosphor *self, double center,
 /* Launch sequence                                                          */
 /* ------------------------------------------------------------------------ */
 
-static void prof_begin(struct fosphor *self, int kind)
+static void prof_begin(struct fosphor *self, int kind, hipStream_t st)
 {
 	if (!self->prof) return;
 	if (self->ev_used + 2 > self->ev_pool.size()) {
@@ -343,14 +368,14 @@ static void prof_begin(struct fosphor *self, int kind)
 		}
 	}
 	self->ev_kind.push_back(kind);
-	(void)hipEventRecord(self->ev_pool[self->ev_used], self->stream);
+	(void)hipEventRecord(self->ev_pool[self->ev_used], st);
 }
 
-static void prof_end(struct fosphor *self)
+static void prof_end(struct fosphor *self, hipStream_t st)
 {
 	if (!self->prof) return;
 	if (self->ev_used + 2 > self->ev_pool.size()) return;
-	(void)hipEventRecord(self->ev_pool[self->ev_used + 1], self->stream);
+	(void)hipEventRecord(self->ev_pool[self->ev_used + 1], st);
 	self->ev_used += 2;
 }
 
@@ -424,7 +449,7 @@ static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } re
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
  * d_bins / d_partial; results land in slot `slot0`.. of hc / live_sum / vmax. */
 static int run_count(struct fosphor *self, int n_batches, int batch, int tile, int slot0,
-                     int t_offset, int weight_batch)
+                     int t_offset, int weight_batch, hipStream_t st)
 {
 	K2Params k2; K2bParams k2b;
 	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
@@ -436,6 +461,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
+	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
 	if (cpb == 1) {
 		k2.chunk_sum = self->d_live_sum + (size_t)slot0 * kN;
@@ -443,18 +469,18 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	} else {
 		k2.chunk_sum = self->d_chunk_sum;
 		k2.chunk_max = self->d_chunk_max;
-		HIP_TRY(hipMemsetAsync(k2.hc, 0, sizeof(uint32_t) * cells * n_batches, self->stream), "zero hit counts");
+		HIP_TRY(hipMemsetAsync(k2.hc, 0, sizeof(uint32_t) * cells * n_batches, st), "zero hit counts");
 	}
-	prof_begin(self, 1);
-	HIP_TRY(launch_k2(k2, n_batches * cpb, self->stream), "launch count");
+	prof_begin(self, 1, st);
+	HIP_TRY(launch_k2(k2, n_batches * cpb, st), "launch count");
 	if (cpb > 1) {
 		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
 		k2b.live_sum = self->d_live_sum + (size_t)slot0 * kN;
 		k2b.vmax = self->d_vmax + (size_t)slot0 * kN;
 		k2b.n_batches = n_batches; k2b.cpb = cpb;
-		HIP_TRY(launch_k2b(k2b, self->stream), "launch chunk reduce");
+		HIP_TRY(launch_k2b(k2b, st), "launch chunk reduce");
 	}
-	prof_end(self);
+	prof_end(self, st);
 	return 0;
 error:
 	return -EIO;
@@ -462,13 +488,14 @@ error:
 
 /* (d, e) of display.cl:241-245 for every possible hit count of a batch.  Same float
  * expressions as the kernel source, powf from the host libm (the oracle's binding). */
-static int ensure_rise_table(struct fosphor *self, int batch)
+static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 {
 	if (batch > kRiseMax)
 		return 0;
 	if (self->rise_batch == batch && self->rise_t0r == self->t0r && self->rise_t0d == self->t0d)
 		return 1;
 	(void)hipStreamSynchronize(self->stream);	/* h_rise may be in flight */
+	(void)hipStreamSynchronize(self->stream2);
 	for (int hc = 0; hc <= batch; hc++) {
 		const float a = (float)hc / (float)batch;
 		const float b = a * (1.0f / self->t0r);
@@ -477,17 +504,17 @@ static int ensure_rise_table(struct fosphor *self, int batch)
 		const float e = powf(1.0f - c, (float)batch);
 		self->h_rise[hc] = make_float2(d, e);
 	}
-	if (hipMemcpyAsync(self->d_rise, self->h_rise, sizeof(float2) * (batch + 1), hipMemcpyHostToDevice, self->stream) != hipSuccess)
+	if (hipMemcpyAsync(self->d_rise, self->h_rise, sizeof(float2) * (batch + 1), hipMemcpyHostToDevice, st) != hipSuccess)
 		return -1;
 	self->rise_batch = batch; self->rise_t0r = self->t0r; self->rise_t0d = self->t0d;
 	return 1;
 }
 
-static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0)
+static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st)
 {
 	K3Params k3;
 	const size_t cells = (size_t)self->n_bins * kN;
-	const int have_table = ensure_rise_table(self, batch);
+	const int have_table = ensure_rise_table(self, batch, st);
 	if (have_table < 0)
 		return -EIO;
 	memset(&k3, 0, sizeof(k3));
@@ -499,9 +526,9 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0)
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
 	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
-	prof_begin(self, 2);
-	HIP_TRY(launch_k3(k3, self->stream), "launch merge");
-	prof_end(self);
+	prof_begin(self, 2, st);
+	HIP_TRY(launch_k3(k3, st), "launch merge");
+	prof_end(self, st);
 	return 0;
 error:
 	return -EIO;
@@ -511,20 +538,42 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
 {
 	const int total = n_batches * batch;
 	const int tile = pick_tile(total);
+	hipStream_t st2 = self->overlap ? self->stream2 : self->stream;
 	K1Params k1;
+	int set;
 
 	if (prepare(self))
 		return -EIO;
 
+	/* Pipeline: K1 (VALU-bound) of this launch runs on `stream` while K2/K3 (memory- and
+	 * latency-bound) of the previous launch still run on `stream2`; the bin-index / partial
+	 * intermediates ping-pong between two sets.  K1 may reuse a set once the K2 that read
+	 * it has finished; K2 starts when its K1 has finished; K3s stay in launch order on
+	 * stream2, so the persistent state sees the batches in order. */
+	set = self->pp;
+	self->pp ^= 1;
+	self->d_bins = self->d_bins_pp[set];
+	self->d_partial = self->d_partial_pp[set];
+	if (self->overlap && self->set_used[set])
+		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
+
 	fill_k1(self, &k1, d_iq, total, tile, self->wf_pos,
 	        total > self->wf_rows ? total - self->wf_rows : 0);
-	prof_begin(self, 0);
+	prof_begin(self, 0, self->stream);
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
-	prof_end(self);
+	prof_end(self, self->stream);
 
-	if (run_count(self, n_batches, batch, tile, 0, 0, batch))
+	if (self->overlap) {
+		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
+		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
+	}
+	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2))
 		return -EIO;
-	if (run_merge(self, n_batches, batch, 0))
+	if (self->overlap) {
+		HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+		self->set_used[set] = 1;
+	}
+	if (run_merge(self, n_batches, batch, 0, st2))
 		return -EIO;
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
@@ -591,7 +640,7 @@ extern "C" int fosphor_amd_finish(struct fosphor *self)
 		if (prepare(self))
 			return -EIO;
 	}
-	if (hipStreamSynchronize(self->stream) != hipSuccess)
+	if (hipStreamSynchronize(self->stream) != hipSuccess || hipStreamSynchronize(self->stream2) != hipSuccess)
 		return -EIO;
 	self->state = ST_READY;
 	return 1;
@@ -658,6 +707,7 @@ extern "C" int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_o
 	int saved_state;
 	if (!self || !d_in || !d_out || n_spectra < 4 || (n_spectra & 3) || n_spectra > self->max_spectra)
 		return -EINVAL;
+	(void)hipStreamSynchronize(self->stream2);	/* scratch sets may still be read by a queued K2 */
 	saved_state = self->state;
 	self->state = ST_READY;			/* no boot fills for a pure FFT */
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -678,6 +728,7 @@ extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_
 	if (!self || !d_fft || !d_bin || !d_pwr || n < 1)
 		return -EINVAL;
 	if (e && *e == '1') force = 1;
+	(void)hipStreamSynchronize(self->stream2);
 	saved_state = self->state;
 	self->state = ST_READY;
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -701,6 +752,11 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	if (!self || !d_samples || n_local < 16 || (n_local & 15) || (t_offset & 15) ||
 	    t_offset < 0 || t_offset + n_local > total_batch || n_local > self->max_spectra)
 		return -EINVAL;
+	if (self->set_used[0] || self->set_used[1]) {
+		/* the split path runs on `stream` only; drain a preceding two-stream launch */
+		(void)hipStreamSynchronize(self->stream2);
+		self->set_used[0] = self->set_used[1] = 0;
+	}
 	if (prepare(self))
 		return -EIO;
 
@@ -709,11 +765,11 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	wf_first = total_batch - self->wf_rows - t_offset;
 	if (wf_first < 0) wf_first = 0;
 	fill_k1(self, &k1, d_samples, n_local, tile, (self->wf_pos + t_offset) & (self->wf_rows - 1), wf_first);
-	prof_begin(self, 0);
+	prof_begin(self, 0, self->stream);
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
-	prof_end(self);
+	prof_end(self, self->stream);
 
-	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch))
+	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch, self->stream))
 		return -EIO;
 
 	/* the ring advances with the data (host state), so the next frame can be accumulated
@@ -752,7 +808,7 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 		return -EINVAL;
 	if (prepare(self))
 		return -EIO;
-	if (run_merge(self, 1, total_batch, self->slot))
+	if (run_merge(self, 1, total_batch, self->slot, self->stream))
 		return -EIO;
 	self->last_batches = 1;
 	self->last_slot0 = self->slot;
@@ -773,7 +829,7 @@ extern "C" int fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int l
 {
 	if (!self)
 		return -EINVAL;
-	if (hipStreamSynchronize(self->stream) != hipSuccess)
+	if (hipStreamSynchronize(self->stream) != hipSuccess || hipStreamSynchronize(self->stream2) != hipSuccess)
 		return -EIO;
 	for (int i = 0; i < 3; i++) { ms[i] = 0.0f; launches[i] = 0; }
 	for (size_t i = 0; i + 1 < self->ev_used; i += 2) {

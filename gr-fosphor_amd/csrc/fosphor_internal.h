@@ -62,6 +62,7 @@ struct K2Params {
 	int   tile;
 	int   n_bins;
 	float w;
+	float log2_w;			/* log2(1 - alpha), host double -> float */
 	/* sharded batch (multi-GPU): this launch holds spectra [t_offset, t_offset+batch)
 	 * of a batch of weight_batch spectra; single GPU: t_offset 0, weight_batch = batch */
 	int   t_offset, weight_batch;

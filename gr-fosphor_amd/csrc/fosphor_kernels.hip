@@ -524,7 +524,8 @@ void k2_count(const K2Params p)
 		for (int j = row; j < tiles; j += 16) {
 			const float2 v = pp[(size_t)j * kN];
 			const int t_last = p.t_offset + t_in + (j + 1) * p.tile - 1;
-			s += v.x * powf(p.w, (float)(p.weight_batch - 1 - t_last));
+			/* (1-a)^k as exp2(k log2(1-a)): relative error ~1e-6 where the weight is not negligible */
+			s += v.x * __builtin_amdgcn_exp2f(p.log2_w * (float)(p.weight_batch - 1 - t_last));
 			m = (m < v.y) ? v.y : m;
 		}
 		red_s[row][col] = s;
