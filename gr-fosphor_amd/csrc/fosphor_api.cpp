@@ -71,9 +71,11 @@ struct fosphor
 	hipEvent_t ev_set_free[2];		/* K2 finished reading set pp */
 	int       set_used[2];
 	int       overlap;			/* 1: two-stream pipeline for process paths */
+	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
+	long long *d_dbg;			/* K1_TIMING builds only (FOSPHOR_AMD_K1_TIMING=1) */
 	float2   *d_rise;			/* [kRiseMax+1] (d, e) per hit count */
 	float2   *h_rise;			/* pinned */
 	int       rise_batch;			/* batch the table was built for (0 = none) */
@@ -183,6 +185,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
+	(void)hipFree(self->d_dbg);
 	if (self->h_rise) (void)hipHostFree(self->h_rise);
 	for (int i = 0; i < 2; i++) {
 		if (self->h_stage[i]) (void)hipHostFree(self->h_stage[i]);
@@ -273,9 +276,15 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
 	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	if (getenv("FOSPHOR_AMD_K1_TIMING")) {
+		HIP_TRY(hipMalloc((void **)&self->d_dbg, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "alloc timing buffer");
+		HIP_TRY(hipMemset(self->d_dbg, 0, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "clear timing buffer");
+	}
 	{
 		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
 		self->overlap = !(e && *e == '0');
+		e = getenv("FOSPHOR_AMD_K1");
+		self->k1_variant = (e && *e == '1') ? 1 : 2;
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
@@ -418,10 +427,14 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 {
 	const double A = (double)self->histo_scale * 0.150514997831990597606869447362;
 	const double C = (double)self->histo_scale * (double)self->histo_offset;
-	/* |v_fast - v_oracle| bound, see DESIGN.md "exact binning": a constant part from the
-	 * float roundings of v itself (v < 256) and a part proportional to histo_scale from
-	 * the log2 approximation on |log2 s| <= 32 */
-	const float delta = 6.0e-5f + 2.2e-6f * self->histo_scale;
+	/* |v_fast - v_pinned| bound, DESIGN.md "exact binning".  Part that does not scale with
+	 * |l2|: the float roundings of v itself and of the pinned chain (v < 256: <= 3e-5) plus
+	 * histo_scale x (pwr, pwr+offset roundings + the mult by log10(2)/2: <= 8e-7), doubled.
+	 * Part proportional to |l2| = |log2 s|: v_log_f32 (<= 1 ulp of l2) and the rounding of
+	 * s32 (<= 1.5 ulp of s -> 2.2e-7 in l2, absorbed for |l2| >= 1 ... and by delta0 below
+	 * that), through the slope A: kappa = 2 x A x 2^-23. */
+	const float delta0 = 6.0e-5f + 2.0e-6f * self->histo_scale;
+	const float kappa = (float)(2.0 * A * 1.1920928955078125e-07);
 
 	memset(k1, 0, sizeof(*k1));
 	k1->iq = (const float2 *)d_iq;
@@ -432,6 +445,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->partial = self->d_partial;
 	k1->wf = self->d_wf;
 	k1->fft_out = NULL;
+	k1->dbg = self->d_dbg;
 	k1->total = total;
 	k1->tile = tile;
 	k1->wf_pos0 = wf_pos0;
@@ -440,8 +454,10 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->n_bins = self->n_bins;
 	k1->binA = (float)A;
 	k1->binC = (float)C;
-	k1->amb = 0.5f - delta;
+	k1->amb = 0.5f - delta0;
+	k1->kappa = kappa;
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
+	k1->variant = self->k1_variant;
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -880,4 +896,14 @@ extern "C" int fosphor_amd_host_twiddles(float *out)
 		return -EINVAL;
 	build_twiddles((float2 *)out);
 	return 0;
+}
+
+/* debug: copy the K1 phase-timing accumulators (K1_TIMING builds) to the host */
+extern "C" int fosphor_amd_debug_k1_timing(struct fosphor *self, long long *out, int n)
+{
+	if (!self || !self->d_dbg || !out || n > 8 * 4 * kK1MaxBlocks)
+		return -EINVAL;
+	if (fosphor_amd_finish(self) < 0)
+		return -EIO;
+	return hipMemcpy(out, self->d_dbg, sizeof(long long) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -EIO;
 }

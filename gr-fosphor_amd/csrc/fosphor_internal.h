@@ -24,6 +24,7 @@ constexpr int kTw4Off = kTw3Off + 64 * 7;
 constexpr int kTwLen  = kTw4Off + 512;
 
 constexpr int kK1MaxBlocks = 512;	/* 256 CUs x 2 resident work-groups of 4 waves */
+constexpr int kK1V2MaxBlocks = 2048;	/* v2: 256 CUs x 8 resident work-groups of 2 waves */
 
 /* K1: IQ -> FFT -> bin index / waterfall row / live+max partials */
 struct K1Params {
@@ -35,14 +36,17 @@ struct K1Params {
 	float2       *partial;		/* [total/tile][N] (live partial, max) */
 	float        *wf;		/* [wf_rows][N] */
 	float2       *fft_out;		/* test hook, or nullptr */
+	long long    *dbg;		/* K1_TIMING builds: [waves][8] cycle accumulators, or nullptr */
 	int   total;			/* spectra in this launch */
 	int   tile;			/* spectra per wave: 4, 8 or 16 */
 	int   wf_pos0, wf_mask;		/* ring position of spectrum 0, wf_rows-1 */
 	int   wf_first;			/* spectra with index < wf_first do not store their row */
 	int   n_bins;
 	float binA, binC;		/* v ~= binA * log2(|X|^2) + binC */
-	float amb;			/* confident when |v - rint(v)| <= amb */
+	float amb;			/* confident when |v - rint(v)| + kappa |l2| <= amb */
+	float kappa;			/* v_log_f32 error bound per unit of |log2 s|, through the slope binA */
 	float w;			/* 1 - alpha */
+	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum */
 };
 
 /* K2: bin indices -> hit counts + live sum / max per column.

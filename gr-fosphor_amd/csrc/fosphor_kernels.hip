@@ -31,44 +31,115 @@ namespace fosphor_amd {
 /* ------------------------------------------------------------------------ */
 /* Complex helpers: same operations, same order as fft.cl                   */
 /* ------------------------------------------------------------------------ */
+/* A complex value is one 64-bit VGPR pair (re, im).  Every helper performs exactly the IEEE
+ * operations of the reference expression it cites -- only the instruction selection differs:
+ * with K1_ASM_PK the half-swaps and sign flips of the reference's "multiply by -j" and of the
+ * complex product ride on VOP3P op_sel / neg modifiers instead of costing v_mov / extra adds.
+ * x - (-y) and x + y are the same IEEE operation, as are a*b and b*a, a+b and b+a.          */
+
+#ifndef K1_ASM_PK
+#define K1_ASM_PK 1
+#endif
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define F_SQRT_1_2 (0.707106781188f)	/* fft.cl:72 */
 
-/* fft.cl:37-46 */
-static __device__ __forceinline__ float2 c_mul(float2 a, float2 b)
+/* fft.cl:37-46 : (a.x*w.x - a.y*w.y, a.x*w.y + a.y*w.x) */
+static __device__ __forceinline__ v2f c_mul(v2f a, v2f w)
 {
-	float2 r;
-	r.x = a.x * b.x - a.y * b.y;
-	r.y = a.x * b.y + a.y * b.x;
+#if K1_ASM_PK
+	v2f t1, t2, r;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(w));			/* (a.x*w.x, a.y*w.x) */
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t2) : "v"(a), "v"(w));	/* (a.y*w.y, a.x*w.y) */
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));			/* (t1.x - t2.x, t1.y + t2.y) */
 	return r;
+#else
+	v2f r;
+	r.x = a.x * w.x - a.y * w.y;
+	r.y = a.x * w.y + a.y * w.x;
+	return r;
+#endif
 }
 
-/* fft.cl:77-82 */
-static __device__ __forceinline__ float2 mul_p1q2(float2 a) { return make_float2(a.y, -a.x); }
-static __device__ __forceinline__ float2 mul_p1q4(float2 a)
+/* a + mul_p1q2(b) and a - mul_p1q2(b), mul_p1q2(b) = (b.y, -b.x)  (fft.cl:77, used by dft8) */
+static __device__ __forceinline__ v2f add_mj(v2f a, v2f b)
 {
-	return make_float2(F_SQRT_1_2 * (a.x + a.y), F_SQRT_1_2 * (-a.x + a.y));
+#if K1_ASM_PK
+	v2f r;
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	v2f r; r.x = a.x + b.y; r.y = a.y + (-b.x); return r;
+#endif
 }
-static __device__ __forceinline__ float2 mul_p3q4(float2 a)
+static __device__ __forceinline__ v2f sub_mj(v2f a, v2f b)
 {
-	return make_float2(F_SQRT_1_2 * (-a.x + a.y), F_SQRT_1_2 * (-a.x - a.y));
+#if K1_ASM_PK
+	v2f r;
+	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+#else
+	v2f r; r.x = a.x - b.y; r.y = a.y - (-b.x); return r;
+#endif
+}
+
+/* fft.cl:80 : SQRT_1_2 * (a.x + a.y, -a.x + a.y) */
+static __device__ __forceinline__ v2f mul_p1q4(v2f a, v2f s12)
+{
+#if K1_ASM_PK
+	v2f t, r;
+	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a));	/* (a.x + a.y, a.y + -a.x) */
+	asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(s12));
+	return r;
+#else
+	v2f r; r.x = s12.x * (a.x + a.y); r.y = s12.y * (-a.x + a.y); return r;
+#endif
+}
+/* fft.cl:82 : SQRT_1_2 * (-a.x + a.y, -a.x - a.y) */
+static __device__ __forceinline__ v2f mul_p3q4(v2f a, v2f s12)
+{
+#if K1_ASM_PK
+	v2f t, r;
+	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(t) : "v"(a));	/* (-a.x + a.y, -a.x + -a.y) */
+	asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(s12));
+	return r;
+#else
+	v2f r; r.x = s12.x * (-a.x + a.y); r.y = s12.y * (-a.x - a.y); return r;
+#endif
 }
 
 /* fft.cl:86-94 */
-#define DFT2(a, b) do { \
-		float2 _t = make_float2((a).x - (b).x, (a).y - (b).y); \
-		(a) = make_float2((a).x + (b).x, (a).y + (b).y); \
-		(b) = _t; \
-	} while (0)
+#define DFT2(a, b) do { v2f _t = (a) - (b); (a) = (a) + (b); (b) = _t; } while (0)
+/* dft2(a, mul_p1q2(b)) */
+#define DFT2_MJ(a, b) do { v2f _t = sub_mj((a), (b)); (a) = add_mj((a), (b)); (b) = _t; } while (0)
 
-/* fft.cl:112-145 */
-static __device__ __forceinline__ void dft8(float2 (&r)[8])
+/* fft.cl:112-145.  The three mul_p1q2 twiddles (r6 after stage 1; r3, r7 after stage 2) are
+ * folded into the butterflies that consume them. */
+static __device__ __forceinline__ void dft8(v2f (&r)[8], v2f s12)
 {
 	DFT2(r[0], r[4]); DFT2(r[1], r[5]); DFT2(r[2], r[6]); DFT2(r[3], r[7]);
-	r[5] = mul_p1q4(r[5]); r[6] = mul_p1q2(r[6]); r[7] = mul_p3q4(r[7]);
-	DFT2(r[0], r[2]); DFT2(r[1], r[3]); DFT2(r[4], r[6]); DFT2(r[5], r[7]);
-	r[3] = mul_p1q2(r[3]); r[7] = mul_p1q2(r[7]);
-	DFT2(r[0], r[1]); DFT2(r[2], r[3]); DFT2(r[4], r[5]); DFT2(r[6], r[7]);
+	r[5] = mul_p1q4(r[5], s12); r[7] = mul_p3q4(r[7], s12);
+	DFT2(r[0], r[2]); DFT2(r[1], r[3]); DFT2_MJ(r[4], r[6]); DFT2(r[5], r[7]);
+	DFT2(r[0], r[1]); DFT2_MJ(r[2], r[3]); DFT2(r[4], r[5]); DFT2_MJ(r[6], r[7]);
+}
+
+/* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
+static __device__ __forceinline__ v2f mul_bcast_lo(v2f x, v2f w)
+{
+#if K1_ASM_PK
+	v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(w)); return r;
+#else
+	v2f r; r.x = x.x * w.x; r.y = x.y * w.x; return r;
+#endif
+}
+static __device__ __forceinline__ v2f mul_bcast_hi(v2f x, v2f w)
+{
+#if K1_ASM_PK
+	v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(w)); return r;
+#else
+	v2f r; r.x = x.x * w.y; r.y = x.y * w.y; return r;
+#endif
 }
 
 /* Order in which a radix-8 pass stores its outputs: offsets {0,p,..,7p} receive
@@ -76,12 +147,28 @@ static __device__ __forceinline__ void dft8(float2 (&r)[8])
 #define R8_PERM(jj) (((jj) == 0) ? 0 : ((jj) == 1) ? 4 : ((jj) == 2) ? 2 : ((jj) == 3) ? 6 : \
                      ((jj) == 4) ? 1 : ((jj) == 5) ? 5 : ((jj) == 6) ? 3 : 7)
 
-/* Intra-wave LDS exchange: program order within the wave is the only ordering needed */
+/* Intra-wave LDS exchange.  All DS instructions of one wave enter the LDS queue in program
+ * order and are executed in that order, so a ds_read issued after the ds_writes of the other
+ * lanes of the SAME wave observes them, and a later ds_write cannot overtake an earlier
+ * ds_read -- no s_waitcnt is needed between the store phase and the load phase of an
+ * exchange (the loads' own lgkmcnt waits before their first use remain).  What must not
+ * happen is the COMPILER moving a load above a store it cannot prove aliases: the wave
+ * barrier + compiler-only memory clobber pin program order without emitting an instruction.
+ * K1_LDS_FENCE=1 restores the conservative release/acquire fences (s_waitcnt lgkmcnt(0)). */
+#ifndef K1_LDS_FENCE
+#define K1_LDS_FENCE 1
+#endif
 static __device__ __forceinline__ void wave_lds_sync()
 {
+#if K1_LDS_FENCE
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+	asm volatile("" ::: "memory");
+	__builtin_amdgcn_wave_barrier();
+	asm volatile("" ::: "memory");
+#endif
 }
 
 /* ------------------------------------------------------------------------ */
@@ -89,14 +176,15 @@ static __device__ __forceinline__ void wave_lds_sync()
 /* ------------------------------------------------------------------------ */
 
 #define F_HALF_LOG10_2 (0.150514997831990597606869447362f)	/* pwr = log10|X| = this * log2(|X|^2) */
+/* Inside K1 the log-power is carried as l2 = log2(|X|^2) and scaled once where it leaves. */
 
 /* Decide a sample the fast path could not: compare |X|^2, formed in double with one
  * rounding (both squares are exact), against the exact thresholds.
  * thr[b] for b in [1, nb) = smallest double s with oracle_bin(s) >= b; thr[0] = -1;
  * thr[nb] = smallest s whose hypot overflows float (-> non-finite -> bin 0,
  * fosphor_portable_math.h fpm_bin_from_pwr). */
-static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float pwr_fast, int guess,
-                                                      const double *__restrict__ thr, int nb, float *pwr_out)
+static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float l2_fast, int guess,
+                                                      const double *__restrict__ thr, int nb, float *l2_out)
 {
 	const double xr = (double)re, xi = (double)im;
 	const double sd = __builtin_fma(xr, xr, xi * xi);
@@ -106,7 +194,7 @@ static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float p
 	if (sf >= 1e-30f && sf <= 1e30f) {
 		/* the guess is within one bin of the truth */
 		bin = guess - (sd < thr[guess] ? 1 : 0) + (sd >= thr[guess + 1] ? 1 : 0);
-		*pwr_out = pwr_fast;
+		*l2_out = l2_fast;
 	} else {
 		/* zero, denormal, huge, inf or NaN: full search, and a log-power that does not
 		 * depend on |X|^2 fitting a float: split sd = m * 2^e, m in [1,2) */
@@ -123,16 +211,16 @@ static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float p
 			bin = lo;
 		}
 		if (__builtin_isinf(re) || __builtin_isinf(im) || sd >= thr[nb]) {
-			*pwr_out = __builtin_inff();		/* hypot(inf, anything) = inf; float hypot overflow */
+			*l2_out = __builtin_inff();		/* hypot(inf, anything) = inf; float hypot overflow */
 		} else if (sd == 0.0) {
-			*pwr_out = -__builtin_inff();		/* log10(0) */
+			*l2_out = -__builtin_inff();		/* log10(0) */
 		} else if (sd != sd) {
-			*pwr_out = __builtin_nanf("");
+			*l2_out = __builtin_nanf("");
 		} else {
 			const unsigned long long u = (unsigned long long)__double_as_longlong(sd);
 			const int e = (int)((u >> 52) & 0x7ff) - 1023;
 			const double m = __longlong_as_double((long long)((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
-			*pwr_out = ((float)e + __builtin_amdgcn_logf((float)m)) * F_HALF_LOG10_2;
+			*l2_out = (float)e + __builtin_amdgcn_logf((float)m);
 		}
 	}
 	if (bin >= nb)
@@ -140,24 +228,43 @@ static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float p
 	return (uint32_t)bin;
 }
 
-struct BinConst { float A, C, amb; int nb; const double *thr; };
+struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
 
-/* Fast path.  Returns the bin guess; *ok says whether it is provably exact. */
-static __device__ __forceinline__ int bin_fast(float re, float im, const BinConst &k, float *pwr, bool *ok)
+/* Fast path.  Returns r = rint(v) (the bin guess before clamping, as a float), l2 = log2(|X|^2)
+ * and the sample's ambiguity measure
+ *     amb = |v - r| + kappa * |l2|
+ * -- distance of the scaled log-power from the bin centre, plus the v_log_f32 error bound
+ * (<= 1 ulp of l2, through the slope A: kappa = 2 * A * 2^-23, the factor 2 is margin; it also
+ * covers the rounding of s32).  The guess is provably exact iff amb <= 0.5 - delta0, delta0
+ * bounding the roundings that do not scale with l2 (DESIGN.md "exact binning").  amb is >= 0,
+ * +inf for |X|^2 in {0, denormal-flushed, inf}, NaN for NaN: compared as an unsigned bit
+ * pattern all of those order above every finite value, so one running v_max_u32 per spectrum
+ * collects "some sample needs the exact path" without per-sample compares or branches. */
+static __device__ __forceinline__ float bin_fast(float re, float im, const BinConst &k, float *l2_out, uint32_t *amb_bits)
 {
 	const float s  = __builtin_fmaf(re, re, im * im);
 	const float l2 = __builtin_amdgcn_logf(s);		/* v_log_f32 */
 	const float v  = __builtin_fmaf(k.A, l2, k.C);
 	const float r  = __builtin_rintf(v);
-	/* clamp in float first (med3; NaN -> 0), so the conversion is always defined */
-	const int g = (int)__builtin_amdgcn_fmed3f(r, 0.0f, (float)(k.nb - 1));
-	*pwr = l2 * F_HALF_LOG10_2;
-	/* confident: well inside a bin, and |X|^2 within [2^-32, 2^32) where the v_log_f32 error
-	 * bound used to size `amb` holds -- one unsigned compare on the exponent field:
-	 * bits(2^-32) = 0x2f800000, bits(2^32) = 0x4f800000.  NaN / inf / 0 / negative fail it. */
-	const unsigned su = __float_as_uint(s);
-	*ok = (__builtin_fabsf(v - r) <= k.amb) & ((su - 0x2f800000u) < 0x20000000u);
-	return g;
+	const float a  = __builtin_fmaf(__builtin_fabsf(l2), k.kappa, __builtin_fabsf(v - r));
+	*l2_out = l2;
+	*amb_bits = __float_as_uint(a);
+	return r;
+}
+
+/* bin byte of a float guess r: saturating float -> u8 (NaN -> 0), capped at nb-1 */
+static __device__ __forceinline__ uint32_t pack_bin(float r, float top, uint32_t byte, uint32_t old)
+{
+	return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fminf(r, top), byte, old);
+}
+
+static __device__ __forceinline__ float max_f32(float a, float b)
+{
+	/* one v_max_f32 (IEEE mode: a NaN operand is dropped = OpenCL max(acc, NaN) keeps acc,
+	 * display.cl:139); fmaxf() would add two canonicalising self-max instructions */
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -175,27 +282,35 @@ static __device__ __forceinline__ int bin_fast(float re, float im, const BinCons
 #define K1_TW3_LDS 0			/* pass-3 twiddles from an LDS table instead of registers */
 #endif
 
-typedef float v2f __attribute__((ext_vector_type(2)));
+/* K1_TIMING=1 (debug builds only, tools/k1_phase_timing.py): s_memtime stamps per phase,
+ * accumulated per wave into K1Params::dbg[wave][phase]. */
+#ifndef K1_TIMING
+#define K1_TIMING 0
+#endif
+#if K1_TIMING
+#define K1_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+		const long long _now = __builtin_readcyclecounter(); tacc[i] += _now - tprev; tprev = _now; } while (0)
+#else
+#define K1_STAMP(i) do { } while (0)
+#endif
 
 /* 16 x (64 lanes x 8 B) coalesced, read-once: non-temporal */
-static __device__ __forceinline__ void load_iq16(float2 (&x)[16], const float2 *__restrict__ src)
+static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__restrict__ src)
 {
 #pragma unroll
-	for (int m = 0; m < 16; m++) {
-		const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + 64 * m));
-		x[m] = make_float2(v.x, v.y);
-	}
+	for (int m = 0; m < 16; m++)
+		x[m] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + 64 * m));
 }
 
 template <bool WRITE_FFT>
 __global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
 void k1_fft_bin(const K1Params p)
 {
-	__shared__ float2 lds[4][kN];			/* 8 KiB exchange slab per wave */
-	__shared__ float2 tw4_tab[512];			/* pass-4 twiddles, shared by the block */
-	__shared__ float  win_tab[kN];			/* window, shared by the block */
+	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
+	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles, shared by the block */
+	__shared__ float win_tab[kN];			/* window, shared by the block */
 #if K1_TW3_LDS
-	__shared__ float2 tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
+	__shared__ v2f   tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
 #endif
 
 	const int lane   = threadIdx.x & 63;
@@ -203,34 +318,36 @@ void k1_fft_bin(const K1Params p)
 	const int ntiles = p.total / p.tile;
 	const int stride = gridDim.x * 4;		/* waves in the grid */
 	int tile = blockIdx.x * 4 + wv;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
 
 	for (int i = threadIdx.x; i < kN; i += 256)
 		win_tab[i] = p.win[i];
 	for (int i = threadIdx.x; i < 512; i += 256)
-		tw4_tab[i] = p.tw[kTw4Off + i];
+		tw4_tab[i] = twg[kTw4Off + i];
 #if K1_TW3_LDS
 	for (int i = threadIdx.x; i < 7 * 64; i += 256)
-		tw3_tab[i % 7][i / 7] = p.tw[kTw3Off + i];
+		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
 #endif
 	__syncthreads();				/* the only block-wide barrier */
 
 	if (tile >= ntiles)
 		return;					/* whole wave leaves */
 
-	float2 *buf = lds[wv];
+	v2f *buf = lds[wv];
 
-	/* ---- per-lane constants, loaded once per tile ------------------------- */
-	float2 tw2[7];
+	/* ---- per-lane constants, loaded once per wave -------------------------- */
+	v2f tw2[7];
 #if !K1_TW3_LDS
-	float2 tw3[7];
+	v2f tw3[7];
 #endif
 #pragma unroll
 	for (int n = 0; n < 7; n++) {
-		tw2[n] = p.tw[kTw2Off + (lane & 7) * 7 + n];	/* k = i & 7  (both virtual items) */
+		tw2[n] = twg[kTw2Off + (lane & 7) * 7 + n];	/* k = i & 7  (both virtual items) */
 #if !K1_TW3_LDS
-		tw3[n] = p.tw[kTw3Off + lane * 7 + n];		/* k = i & 63 = lane               */
+		tw3[n] = twg[kTw3Off + lane * 7 + n];		/* k = i & 63 = lane               */
 #endif
 	}
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
 
 	/* ---- swizzled LDS addressing -------------------------------------------
 	 * element e lives at phys(e) = e ^ ((e >> 3) & 15): every access below is
@@ -242,22 +359,28 @@ void k1_fft_bin(const K1Params p)
 	const int st1     = (8 * lane) ^ (lane & 15);		/* pass 1: e = 8i + jj    */
 	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);	/* pass 2: e = 64(i>>3)+(i&7)+8jj */
 
-	const BinConst bk = { p.binA, p.binC, p.amb, p.n_bins, p.thr };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;	/* display.cl:91, in log2 units */
 
-	float2 xn[16];
+	v2f xn[16];
 #if K1_PREFETCH
 	load_iq16(xn, p.iq + (size_t)tile * p.tile * kN + lane);
+#endif
+#if K1_TIMING
+	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	long long tprev = __builtin_readcyclecounter();
 #endif
 
 	/* persistent wave: tiles tile, tile + stride, ... (per-lane constants stay in registers) */
 	for (; tile < ntiles; tile += stride) {
 	const int t0 = tile * p.tile;
 
+	/* live partial and running max of this tile, in log2(|X|^2) units */
 	float live[16], vmax[16];
 #pragma unroll
 	for (int m = 0; m < 16; m++) {
 		live[m] = 0.0f;
-		vmax[m] = -1000.0f;				/* display.cl:91 */
+		vmax[m] = vmax_init;
 	}
 
 	for (int g0 = 0; g0 < p.tile; g0 += 4) {
@@ -269,17 +392,20 @@ void k1_fft_bin(const K1Params p)
 #pragma unroll 1
 		for (int u = 0; u < 4; u++) {
 			const int t = t0 + g0 + u;
-			float2 x[16];
+			v2f x[16];
 
 #if !K1_PREFETCH
 			load_iq16(xn, p.iq + (size_t)t * kN + lane);
 #endif
-			/* window (fft.cl:415-417) */
+			K1_STAMP(7);		/* loop overhead + stores of the previous iteration */
+			/* window (fft.cl:415-417); taps fetched as pairs (m, m+1) */
 #pragma unroll
-			for (int m = 0; m < 16; m++)
-			{
-				const float w = win_tab[lane + 64 * m];
-				x[m] = make_float2(xn[m].x * w, xn[m].y * w);
+			for (int m = 0; m < 16; m += 2) {
+				v2f w;
+				w.x = win_tab[lane + 64 * m];
+				w.y = win_tab[lane + 64 * (m + 1)];
+				x[m]     = mul_bcast_lo(xn[m], w);
+				x[m + 1] = mul_bcast_hi(xn[m + 1], w);
 			}
 
 #if K1_PREFETCH
@@ -292,15 +418,16 @@ void k1_fft_bin(const K1Params p)
 			}
 #endif
 
+			K1_STAMP(0);		/* window (includes waiting for the prefetched IQ) + prefetch issue */
 			/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) --------
 			 * virtual work-item i = lane + 64v owns elements i + 128j = lane + 64(v + 2j) */
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
-				float2 r[8];
+				v2f r[8];
 #pragma unroll
 				for (int j = 0; j < 8; j++)
 					r[j] = x[v + 2 * j];
-				dft8(r);
+				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
 					buf[(st1 ^ jj) + 512 * v] = r[R8_PERM(jj)];
@@ -311,15 +438,16 @@ void k1_fft_bin(const K1Params p)
 				x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
 			wave_lds_sync();
 
+			K1_STAMP(1);		/* pass 1 + exchange */
 			/* ---- pass 2: radix 8, p = 8 (fft.cl:422-423) ------------------- */
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
-				float2 r[8];
+				v2f r[8];
 				r[0] = x[v];
 #pragma unroll
 				for (int j = 1; j < 8; j++)
 					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
-				dft8(r);
+				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
 					buf[(st2 ^ (9 * jj)) + 512 * v] = r[R8_PERM(jj)];
@@ -330,10 +458,11 @@ void k1_fft_bin(const K1Params p)
 				x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
 			wave_lds_sync();
 
+			K1_STAMP(2);		/* pass 2 + exchange */
 			/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426) ------------------ */
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
-				float2 r[8];
+				v2f r[8];
 				r[0] = x[v];
 #pragma unroll
 				for (int j = 1; j < 8; j++)
@@ -342,7 +471,7 @@ void k1_fft_bin(const K1Params p)
 #else
 					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
 #endif
-				dft8(r);
+				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)	/* e = 512v + lane + 64jj */
 					buf[((jj & 1) ? rd_odd : rd_even) + 64 * jj + 512 * v] = r[R8_PERM(jj)];
@@ -353,66 +482,68 @@ void k1_fft_bin(const K1Params p)
 				x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
 			wave_lds_sync();
 
+			K1_STAMP(3);		/* pass 3 + exchange */
 			/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) ------------------
 			 * butterfly on elements (j, j + 512), j = lane + 64c, twiddle k = j.
 			 * Results: X[j] -> x[c], X[j + 512] -> x[c + 8], i.e. column lane + 64m. */
 #pragma unroll
 			for (int c = 0; c < 8; c++) {
-				float2 a = x[c];
-				float2 b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);	/* k = lane + 64c */
+				v2f a = x[c];
+				v2f b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);	/* k = lane + 64c */
 				DFT2(a, b);
 				x[c] = a;
 				x[c + 8] = b;
 			}
 
+			K1_STAMP(4);		/* pass 4 */
 			if (WRITE_FFT) {
 #pragma unroll
 				for (int m = 0; m < 16; m++)
-					p.fft_out[(size_t)t * kN + lane + 64 * m] = x[m];
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * m] = x[m];
 			}
 
-			/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) ----
-			 * in chunks of 4 columns to keep the live register set small */
+			/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) ---- */
+			float    l2[16];
+			uint32_t amb = 0;
+			const float top = (float)(bk.nb - 1);
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				uint32_t ab;
+				const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
+				amb = amb > ab ? amb : ab;			/* v_max_u32: NaN / inf propagate */
+				pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+			}
+			if (amb > __float_as_uint(bk.amb)) {
+				/* rare (a few % of spectra have one such sample): find the samples, decide them
+				 * against the exact thresholds, patch their bin byte and log-power */
+#pragma unroll
+				for (int m = 0; m < 16; m++) {
+					const float v = __builtin_fmaf(bk.A, l2[m], bk.C);
+					const float r = __builtin_rintf(v);
+					const float a = __builtin_fmaf(__builtin_fabsf(l2[m]), bk.kappa, __builtin_fabsf(v - r));
+					if (!(a <= bk.amb)) {
+						const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
+						float nl2;
+						const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
+						pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
+						l2[m] = nl2;
+					}
+				}
+			}
+
 			const bool store_row = (t >= p.wf_first);
 			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
 #pragma unroll
-			for (int m0 = 0; m0 < 16; m0 += 4) {
-				float    pw[4];
-				uint32_t bn[4];
-				uint32_t redo = 0;
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					bool ok;
-					bn[q] = (uint32_t)bin_fast(x[m0 + q].x, x[m0 + q].y, bk, &pw[q], &ok);
-					redo |= ok ? 0u : (1u << q);
-				}
-				while (redo) {		/* rare: ~2e-4 of samples; one code copy per chunk */
-					const int q = __builtin_ctz(redo);
-					const float    sre = q == 0 ? x[m0].x : q == 1 ? x[m0 + 1].x : q == 2 ? x[m0 + 2].x : x[m0 + 3].x;
-					const float    sim = q == 0 ? x[m0].y : q == 1 ? x[m0 + 1].y : q == 2 ? x[m0 + 2].y : x[m0 + 3].y;
-					const float    spw = q == 0 ? pw[0] : q == 1 ? pw[1] : q == 2 ? pw[2] : pw[3];
-					const uint32_t sbn = q == 0 ? bn[0] : q == 1 ? bn[1] : q == 2 ? bn[2] : bn[3];
-					float npw;
-					const uint32_t nbn = bin_exact(sre, sim, spw, (int)sbn, bk.thr, bk.nb, &npw);
-#pragma unroll
-					for (int qq = 0; qq < 4; qq++) {
-						bn[qq] = (q == qq) ? nbn : bn[qq];
-						pw[qq] = (q == qq) ? npw : pw[qq];
-					}
-					redo &= redo - 1;
-				}
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const int m = m0 + q;
-					pack[m] |= bn[q] << (8 * u);
-					live[m] = __builtin_fmaf(live[m], p.w, pw[q]);		/* Horner form of display.cl:149-150 (tolerance-checked float) */
-					vmax[m] = __builtin_fmaxf(vmax[m], pw[q]);		/* = OpenCL max() here: NaN pwr is ignored, display.cl:139 */
-					if (store_row)
-						wf_row[64 * m] = pw[q];				/* display.cl:142-146 */
-				}
+			for (int m = 0; m < 16; m++) {
+				live[m] = __builtin_fmaf(live[m], p.w, l2[m]);	/* Horner form of display.cl:149-150 */
+				vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
+				if (store_row)
+					wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
 			}
+			K1_STAMP(6);		/* epilogue */
 		}
 
+		K1_STAMP(5);			/* 4th epilogue (the first three land in 7) */
 		/* 4 spectra x 1 column per dword, coalesced 256 B per instruction */
 		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
 #pragma unroll
@@ -420,16 +551,282 @@ void k1_fft_bin(const K1Params p)
 			dst[64 * m] = pack[m];
 	}
 
+	/* leave the log2 domain: pwr = log10|X| = l2 * log10(2)/2; an untouched max is exactly -1000 */
 	float2 *pp = p.partial + (size_t)tile * kN + lane;
 #pragma unroll
 	for (int m = 0; m < 16; m++)
-		pp[64 * m] = make_float2(live[m], vmax[m]);
+		pp[64 * m] = make_float2(live[m] * F_HALF_LOG10_2,
+		                         (vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
+	}	/* tile loop */
+#if K1_TIMING
+	if (p.dbg && lane == 0) {
+		const int w = blockIdx.x * 4 + wv;
+		for (int i = 0; i < 8; i++)
+			p.dbg[w * 8 + i] = tacc[i];
+	}
+#endif
+}
+
+/* ------------------------------------------------------------------------ */
+/* K1 v2: two waves per spectrum                                             */
+/* ------------------------------------------------------------------------ */
+/* Same arithmetic, same LDS layout, same outputs as k1_fft_bin, but a spectrum is shared by
+ * the two waves of a 128-thread work-group exactly like the reference's 128 work-items
+ * (fft.cl:403: WG_SIZE = N/8): lane l of wave w IS virtual work-item i = l + 64w and owns 8
+ * points.  Every per-lane array halves (x, prefetch, l2, live/max, pack), which fits
+ * 4 waves per SIMD without spills; the price is one 2-wave s_barrier per exchange.
+ * After pass 3 wave w takes the pass-4 butterflies c in [4w, 4w+4), i.e. columns
+ * lane + 64m for m in {4w..4w+3} U {8+4w..8+4w+3}. */
+#ifndef K1V2_WAVES_PER_SIMD
+#define K1V2_WAVES_PER_SIMD 3
+#endif
+#ifndef K1V2_TW_LDS
+#define K1V2_TW_LDS 0			/* 1: pass-3 twiddles from LDS; 2: pass-2 and pass-3 */
+#endif
+
+static __device__ __forceinline__ void load_iq8(v2f (&x)[8], const float2 *__restrict__ src)
+{
+#pragma unroll
+	for (int j = 0; j < 8; j++)		/* elements i + 128 j */
+		x[j] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + 128 * j));
+}
+
+template <bool WRITE_FFT>
+__global__ __launch_bounds__(128, K1V2_WAVES_PER_SIMD)
+void k1v2_fft_bin(const K1Params p)
+{
+	__shared__ v2f   buf[kN];			/* 8 KiB exchange slab of the work-group's spectrum */
+	__shared__ v2f   tw4_tab[512];
+	__shared__ float win_tab[kN];
+#if K1V2_TW_LDS >= 1
+	__shared__ v2f   tw3_tab[7][64];		/* [n-1][k] */
+#endif
+#if K1V2_TW_LDS >= 2
+	__shared__ v2f   tw2_tab[7][8];
+#endif
+
+	const int lane   = threadIdx.x & 63;
+	const int w      = threadIdx.x >> 6;		/* wave = virtual-item half */
+	const int i0     = threadIdx.x;			/* virtual work-item i = lane + 64w */
+	const int ntiles = p.total / p.tile;
+	const int stride = gridDim.x;
+	int tile = blockIdx.x;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+
+	for (int i = threadIdx.x; i < kN; i += 128)
+		win_tab[i] = p.win[i];
+	for (int i = threadIdx.x; i < 512; i += 128)
+		tw4_tab[i] = twg[kTw4Off + i];
+#if K1V2_TW_LDS >= 1
+	for (int i = threadIdx.x; i < 7 * 64; i += 128)
+		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
+#endif
+#if K1V2_TW_LDS >= 2
+	if (threadIdx.x < 56)
+		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
+#endif
+	__syncthreads();
+
+	/* per-lane twiddles: k = i & 7 and k = i & 63 do not depend on w */
+#if K1V2_TW_LDS < 2
+	v2f tw2[7];
+#endif
+#if K1V2_TW_LDS < 1
+	v2f tw3[7];
+#endif
+#pragma unroll
+	for (int n = 0; n < 7; n++) {
+#if K1V2_TW_LDS < 2
+		tw2[n] = twg[kTw2Off + (lane & 7) * 7 + n];
+#endif
+#if K1V2_TW_LDS < 1
+		tw3[n] = twg[kTw3Off + lane * 7 + n];
+#endif
+	}
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+
+	/* swizzled addressing, as in k1_fft_bin with v = w */
+	const int rd_even = lane ^ ((lane >> 3) & 7);
+	const int rd_w    = w ? (rd_even ^ 8) : rd_even;		/* e = lane + 64(w + 2j): parity of m is w */
+	const int st1     = ((8 * lane) ^ (lane & 15)) + 512 * w;
+	const int st2     = (((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8)) + 512 * w;
+	const int st3     = 512 * w;					/* + (odd jj ? rd_odd : rd_even) + 64 jj */
+	const int rd_odd  = rd_even ^ 8;
+
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	v2f xn[8];
+	if (tile < ntiles)
+		load_iq8(xn, p.iq + (size_t)tile * p.tile * kN + i0);
+
+	for (; tile < ntiles; tile += stride) {		/* uniform over the work-group */
+	const int t0 = tile * p.tile;
+
+	float live[8], vmax[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		live[q] = 0.0f;
+		vmax[q] = vmax_init;
+	}
+
+	for (int g0 = 0; g0 < p.tile; g0 += 4) {
+		uint32_t pack[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			pack[q] = 0;
+
+#pragma unroll 1
+		for (int u = 0; u < 4; u++) {
+			const int t = t0 + g0 + u;
+			v2f r[8];
+
+			/* window (fft.cl:415-417) */
+#pragma unroll
+			for (int j = 0; j < 8; j += 2) {
+				v2f ww;
+				ww.x = win_tab[i0 + 128 * j];
+				ww.y = win_tab[i0 + 128 * (j + 1)];
+				r[j]     = mul_bcast_lo(xn[j], ww);
+				r[j + 1] = mul_bcast_hi(xn[j + 1], ww);
+			}
+			{	/* prefetch the next spectrum of this work-group */
+				const bool last = (g0 + u + 1 == p.tile);
+				const int t_next = last ? (tile + stride) * p.tile : t + 1;
+				if (!last || tile + stride < ntiles)
+					load_iq8(xn, p.iq + (size_t)t_next * kN + i0);
+			}
+
+			/* pass 1 (fft.cl:419-420) */
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[st1 ^ jj] = r[R8_PERM(jj)];
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = buf[rd_w + 64 * (w + 2 * j)];
+			__syncthreads();
+
+			/* pass 2 (fft.cl:422-423) */
+#pragma unroll
+			for (int j = 1; j < 8; j++)
+#if K1V2_TW_LDS >= 2
+				r[j] = c_mul(r[j], tw2_tab[j - 1][lane & 7]);
+#else
+				r[j] = c_mul(r[j], tw2[j - 1]);
+#endif
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[st2 ^ (9 * jj)] = r[R8_PERM(jj)];
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = buf[rd_w + 64 * (w + 2 * j)];
+			__syncthreads();
+
+			/* pass 3 (fft.cl:425-426) */
+#pragma unroll
+			for (int j = 1; j < 8; j++)
+#if K1V2_TW_LDS >= 1
+				r[j] = c_mul(r[j], tw3_tab[j - 1][lane]);
+#else
+				r[j] = c_mul(r[j], tw3[j - 1]);
+#endif
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[st3 + ((jj & 1) ? rd_odd : rd_even) + 64 * jj] = r[R8_PERM(jj)];
+			__syncthreads();
+
+			/* pass 4 (fft.cl:428-458): butterflies c = 4w + q on elements (j, j+512), j = lane + 64c.
+			 * x[q] = X[lane + 64(4w+q)], x[q+4] = X[lane + 64(8+4w+q)] */
+			v2f x[8];
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int c = 4 * w + q;		/* parity of c is parity of q */
+				v2f a = buf[((q & 1) ? rd_odd : rd_even) + 64 * c];
+				v2f b = buf[((q & 1) ? rd_odd : rd_even) + 64 * (c + 8)];
+				b = c_mul(b, tw4_tab[lane + 64 * c]);
+				DFT2(a, b);
+				x[q] = a;
+				x[q + 4] = b;
+			}
+			__syncthreads();		/* the slab is rewritten by the next spectrum's pass 1 */
+
+			if (WRITE_FFT) {
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * (4 * w + q)] = x[q];
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * (8 + 4 * w + q)] = x[q + 4];
+				}
+			}
+
+			/* epilogue (display.cl:136,161-168), as in k1_fft_bin */
+			float    l2[8];
+			uint32_t amb = 0;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint32_t ab;
+				const float rr = bin_fast(x[q].x, x[q].y, bk, &l2[q], &ab);
+				amb = amb > ab ? amb : ab;
+				pack[q] = pack_bin(rr, top, (uint32_t)u, pack[q]);
+			}
+			if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const float v = __builtin_fmaf(bk.A, l2[q], bk.C);
+					const float rr = __builtin_rintf(v);
+					const float a = __builtin_fmaf(__builtin_fabsf(l2[q]), bk.kappa, __builtin_fabsf(v - rr));
+					if (!(a <= bk.amb)) {
+						const int guess = (int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
+						float nl2;
+						const uint32_t nbn = bin_exact(x[q].x, x[q].y, l2[q], guess, bk.thr, bk.nb, &nl2);
+						pack[q] = (pack[q] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
+						l2[q] = nl2;
+					}
+				}
+			}
+
+			const bool store_row = (t >= p.wf_first);
+			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane + 256 * w;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				live[q] = __builtin_fmaf(live[q], p.w, l2[q]);
+				vmax[q] = max_f32(vmax[q], l2[q]);
+				if (store_row)
+					wf_row[64 * (q & 3) + 512 * (q >> 2)] = l2[q] * F_HALF_LOG10_2;
+			}
+		}
+
+		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane + 256 * w;
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			dst[64 * (q & 3) + 512 * (q >> 2)] = pack[q];
+	}
+
+	float2 *pp = p.partial + (size_t)tile * kN + lane + 256 * w;
+#pragma unroll
+	for (int q = 0; q < 8; q++)
+		pp[64 * (q & 3) + 512 * (q >> 2)] = make_float2(live[q] * F_HALF_LOG10_2,
+			(vmax[q] == vmax_init) ? -1000.0f : vmax[q] * F_HALF_LOG10_2);
 	}	/* tile loop */
 }
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s)
 {
-	const int tiles  = p.total / p.tile;
+	const int tiles = p.total / p.tile;
+	if (p.variant == 2) {
+		const int maxb = 256 * 2 * K1V2_WAVES_PER_SIMD;	/* resident 2-wave work-groups on 256 CUs */
+		int blocks = tiles < maxb ? tiles : maxb;
+		if (p.fft_out)
+			hipLaunchKernelGGL(k1v2_fft_bin<true>, dim3(blocks), dim3(128), 0, s, p);
+		else
+			hipLaunchKernelGGL(k1v2_fft_bin<false>, dim3(blocks), dim3(128), 0, s, p);
+		return hipGetLastError();
+	}
 	int blocks = (tiles + 3) / 4;
 	if (blocks > kK1MaxBlocks)
 		blocks = kK1MaxBlocks;		/* persistent: 2 work-groups per CU */
@@ -445,15 +842,17 @@ __global__ __launch_bounds__(256)
 void k_bin_hook(const float2 *__restrict__ fft, uint8_t *__restrict__ bin, float *__restrict__ pwr, int n,
                 const K1Params p, int force_exact)
 {
-	const BinConst bk = { p.binA, p.binC, p.amb, p.n_bins, p.thr };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float top = (float)(bk.nb - 1);
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		float2 v = fft[i];
-		float pw; bool ok;
-		uint32_t b = (uint32_t)bin_fast(v.x, v.y, bk, &pw, &ok);
-		if (!ok || force_exact)
-			b = bin_exact(v.x, v.y, pw, (int)b, bk.thr, bk.nb, &pw);
+		float l2; uint32_t ab;
+		const float r = bin_fast(v.x, v.y, bk, &l2, &ab);
+		uint32_t b = pack_bin(r, top, 0, 0) & 0xff;
+		if (ab > __float_as_uint(bk.amb) || force_exact)
+			b = bin_exact(v.x, v.y, l2, (int)__builtin_amdgcn_fmed3f(r, 0.0f, top), bk.thr, bk.nb, &l2);
 		bin[i] = (uint8_t)b;
-		pwr[i] = pw;
+		pwr[i] = l2 * F_HALF_LOG10_2;
 	}
 }
 
