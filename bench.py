@@ -153,6 +153,19 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ms, launches = f.kernel_times()
+
+    # K1 alone (same launches, K2/K3 not running beside it): a short extra pass outside the
+    # timed region, reported as roofline.isolated
+    iso = None
+    if mode == "batch":
+        f.set_overlap(False)
+        run_steps(2 * F, 0)
+        f.kernel_times()
+        run_steps(4 * F, 0)
+        ms_i, n_i = f.kernel_times()
+        f.set_overlap(True)
+        if n_i[0]:
+            iso = ms_i[0] / n_i[0]
     f.profile(False)
 
     if world > 1:
@@ -169,6 +182,11 @@ def main():
         achieved = BYTES_PER_SAMPLE * samples_per_launch / (k1_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+        isolated = None
+        if iso:
+            a_i = BYTES_PER_SAMPLE * F * samples_per_batch / (iso * 1e-3) / 1e9
+            isolated = {"k1_ms_per_launch": iso, "achieved": a_i, "frac": a_i / HBM_PEAK_GBS,
+                        "note": "K1 with K2/K3 not running beside it (single stream), outside the timed region"}
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
@@ -189,12 +207,13 @@ def main():
                 "input": "white complex Gaussian sigma=0.05, fp32 IQ resident in HBM (%d MiB ring)" % (ring * 8),
                 "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d steps" % F,
             },
-            "roofline": {"bound": "hbm", "kernel": "k1_fft_bin", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k1v2_fft_bin (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
                          "k2_ms_per_launch": ms[1] / max(1, launches[1]),
                          "k3_ms_per_launch": ms[2] / max(1, launches[2]),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch,
+                         "isolated": isolated},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_seconds)

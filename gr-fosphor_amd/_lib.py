@@ -84,6 +84,7 @@ SIGNATURES = {
     "fosphor_amd_host_thresholds": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "fosphor_amd_host_twiddle_count": (C.c_int, []),
     "fosphor_amd_host_twiddles": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
 }

@@ -150,6 +150,9 @@ class Fosphor:
     def profile(self, enable=True):
         self.L.fosphor_amd_profile(self.h, 1 if enable else 0)
 
+    def set_overlap(self, enable):
+        return self.L.fosphor_amd_set_overlap(self.h, 1 if enable else 0)
+
     def kernel_times(self):
         ms = (C.c_float * 3)()
         n = (C.c_int * 3)()

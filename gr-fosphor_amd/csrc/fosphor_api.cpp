@@ -35,6 +35,8 @@ using namespace fosphor_amd;
 
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
+static const int kSets = 2;		/* intermediate (bin index / partial) sets in rotation */
+
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
 
 struct fosphor
@@ -61,15 +63,15 @@ struct fosphor
 	double   *d_thr;
 	float    *d_wf, *d_hist;
 	float2   *d_spectrum;
-	uint32_t *d_bins_pp[2];			/* ping-pong: K1 of launch i+1 overlaps K2/K3 of launch i */
-	float2   *d_partial_pp[2];
+	uint32_t *d_bins_pp[kSets];		/* rotating sets: K1 of launch i+1 overlaps K2/K3 of launch i */
+	float2   *d_partial_pp[kSets];
 	uint32_t *d_bins;			/* current set */
 	float2   *d_partial;
 	int       pp;
 	hipStream_t stream2;			/* K2/K3 of the multi-batch path */
-	hipEvent_t ev_k1_done[2];		/* K1 wrote set pp */
-	hipEvent_t ev_set_free[2];		/* K2 finished reading set pp */
-	int       set_used[2];
+	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
+	hipEvent_t ev_set_free[kSets];		/* K2 finished reading set pp */
+	int       set_used[kSets];
 	int       overlap;			/* 1: two-stream pipeline for process paths */
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
@@ -175,7 +177,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		(void)hipStreamSynchronize(self->stream);
 	(void)hipFree(self->d_win); (void)hipFree(self->d_tw); (void)hipFree(self->d_thr);
 	(void)hipFree(self->d_wf); (void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < kSets; i++) {
 		(void)hipFree(self->d_bins_pp[i]); (void)hipFree(self->d_partial_pp[i]);
 		if (self->ev_k1_done[i]) (void)hipEventDestroy(self->ev_k1_done[i]);
 		if (self->ev_set_free[i]) (void)hipEventDestroy(self->ev_set_free[i]);
@@ -267,7 +269,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * kN), "alloc waterfall");
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * kN), "alloc histogram");
 	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * kN), "alloc spectrum");
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < kSets; i++) {
 		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * kN), "alloc bin indices");
 		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * kN), "alloc partials");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], hipEventDisableTiming), "create event");
@@ -416,6 +418,9 @@ error:
 
 static int pick_tile(int total)
 {
+	const char *e = getenv("FOSPHOR_AMD_TILE");
+	if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16))
+		return atoi(e);
 	/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
 	if (total / 16 >= 2048) return 16;
 	if (total / 8 >= 2048) return 8;
@@ -567,10 +572,10 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
 	 * it has finished; K2 starts when its K1 has finished; K3s stay in launch order on
 	 * stream2, so the persistent state sees the batches in order. */
 	set = self->pp;
-	self->pp ^= 1;
+	self->pp = (self->pp + 1) % kSets;
 	self->d_bins = self->d_bins_pp[set];
 	self->d_partial = self->d_partial_pp[set];
-	if (self->overlap && self->set_used[set])
+	if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
 		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
 
 	fill_k1(self, &k1, d_iq, total, tile, self->wf_pos,
@@ -906,4 +911,17 @@ extern "C" int fosphor_amd_debug_k1_timing(struct fosphor *self, long long *out,
 	if (fosphor_amd_finish(self) < 0)
 		return -EIO;
 	return hipMemcpy(out, self->d_dbg, sizeof(long long) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -EIO;
+}
+
+/* Two-stream pipelining of the process paths on (1, default) or off (0: K1, K2, K3 in order on
+ * one stream).  Drains queued work first.  Results are identical either way. */
+extern "C" int fosphor_amd_set_overlap(struct fosphor *self, int enable)
+{
+	if (!self)
+		return -EINVAL;
+	if (fosphor_amd_finish(self) < 0)
+		return -EIO;
+	self->overlap = enable ? 1 : 0;
+	self->set_used[0] = self->set_used[1] = 0;
+	return 0;
 }

@@ -145,6 +145,11 @@ int fosphor_amd_host_thresholds(int n_bins, float histo_scale, float histo_offse
 int fosphor_amd_host_twiddle_count(void);
 int fosphor_amd_host_twiddles(float *out);
 
+/* Pipelining of fosphor_process / fosphor_amd_process_device: with overlap on (default) K2/K3
+ * of launch i run on a second stream next to K1 of launch i+1.  0 = strictly one stream.
+ * Results are identical; used by the bench to time K1 in isolation. */
+int fosphor_amd_set_overlap(struct fosphor *self, int enable);
+
 /* hipStream_t the instance runs on. */
 void *fosphor_amd_stream(struct fosphor *self);
 
