@@ -70,6 +70,7 @@ SIGNATURES = {
     # include/fosphor_amd.h
     "fosphor_amd_init": (C.c_void_p, [C.POINTER(Config)]),
     "fosphor_amd_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fosphor_amd_process_device_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_finish": (C.c_int, [C.c_void_p]),
     "fosphor_amd_get_buffers": (C.c_int, [C.c_void_p, C.POINTER(Buffers)]),
     "fosphor_amd_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),

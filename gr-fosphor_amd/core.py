@@ -80,6 +80,10 @@ class Fosphor:
     def process_device(self, d_samples, n_batches, batch):
         return self.L.fosphor_amd_process_device(self.h, _ptr(d_samples), int(n_batches), int(batch))
 
+    def process_device_overlap(self, d_samples, n_batches, batch, overlap):
+        """overlap_cc(wlen=N, overlap) fused into the read (unexpanded stream in HBM)."""
+        return self.L.fosphor_amd_process_device_overlap(self.h, _ptr(d_samples), int(n_batches), int(batch), int(overlap))
+
     def finish(self):
         return self.L.fosphor_amd_finish(self.h)
 

@@ -428,7 +428,7 @@ static int pick_tile(int total)
 }
 
 static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int total, int tile,
-                    int wf_pos0, int wf_first)
+                    int wf_pos0, int wf_first, int hop = kN)
 {
 	const double A = (double)self->histo_scale * 0.150514997831990597606869447362;
 	const double C = (double)self->histo_scale * (double)self->histo_offset;
@@ -443,6 +443,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 
 	memset(k1, 0, sizeof(*k1));
 	k1->iq = (const float2 *)d_iq;
+	k1->hop = hop;
 	k1->win = self->d_win;
 	k1->tw = self->d_tw;
 	k1->thr = self->d_thr;
@@ -555,7 +556,7 @@ error:
 	return -EIO;
 }
 
-static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
+static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch, int hop = kN)
 {
 	const int total = n_batches * batch;
 	const int tile = pick_tile(total);
@@ -579,7 +580,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch)
 		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
 
 	fill_k1(self, &k1, d_iq, total, tile, self->wf_pos,
-	        total > self->wf_rows ? total - self->wf_rows : 0);
+	        total > self->wf_rows ? total - self->wf_rows : 0, hop);
 	prof_begin(self, 0, self->stream);
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
 	prof_end(self, self->stream);
@@ -613,6 +614,22 @@ extern "C" int fosphor_amd_process_device(struct fosphor *self, const void *d_sa
 	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
 		return -EINVAL;
 	return run(self, d_samples, n_batches, batch);
+}
+
+/* overlap_cc (lib/overlap_cc_impl.cc:48-79) emits wlen-sample windows whose starts advance
+ * wlen/overlap input samples, i.e. it materialises an overlap-times larger stream for the sink.
+ * Here the same windows are read straight from the unexpanded stream: spectrum t starts at
+ * sample t * N / overlap, so the unique HBM read per FFT'd sample drops to 8/overlap bytes. */
+extern "C" int fosphor_amd_process_device_overlap(struct fosphor *self, const void *d_samples,
+                                                  int n_batches, int batch, int overlap)
+{
+	if (!self || !d_samples || n_batches < 1 || batch < 16 || (batch & 15))
+		return -EINVAL;
+	if (overlap < 1 || overlap > kN || (kN % overlap))
+		return -EINVAL;
+	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
+		return -EINVAL;
+	return run(self, d_samples, n_batches, batch, kN / overlap);
 }
 
 extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)

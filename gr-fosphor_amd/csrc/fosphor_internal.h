@@ -28,7 +28,8 @@ constexpr int kK1V2MaxBlocks = 2048;	/* v2: 256 CUs x 8 resident work-groups of 
 
 /* K1: IQ -> FFT -> bin index / waterfall row / live+max partials */
 struct K1Params {
-	const float2 *iq;		/* [total][N] */
+	const float2 *iq;		/* spectrum t = iq[t*hop .. t*hop + N) */
+	int   hop;			/* samples between spectrum starts: N, or N/overlap (overlap_cc_impl.cc:74-76) */
 	const float  *win;		/* [N] */
 	const float2 *tw;		/* [kTwLen] */
 	const double *thr;		/* [n_bins + 1] exact squared-magnitude thresholds */

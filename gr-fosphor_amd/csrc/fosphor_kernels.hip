@@ -364,7 +364,7 @@ void k1_fft_bin(const K1Params p)
 
 	v2f xn[16];
 #if K1_PREFETCH
-	load_iq16(xn, p.iq + (size_t)tile * p.tile * kN + lane);
+	load_iq16(xn, p.iq + (size_t)tile * p.tile * p.hop + lane);
 #endif
 #if K1_TIMING
 	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -395,7 +395,7 @@ void k1_fft_bin(const K1Params p)
 			v2f x[16];
 
 #if !K1_PREFETCH
-			load_iq16(xn, p.iq + (size_t)t * kN + lane);
+			load_iq16(xn, p.iq + (size_t)t * p.hop + lane);
 #endif
 			K1_STAMP(7);		/* loop overhead + stores of the previous iteration */
 			/* window (fft.cl:415-417); taps fetched as pairs (m, m+1) */
@@ -414,7 +414,7 @@ void k1_fft_bin(const K1Params p)
 				const bool last = (g0 + u + 1 == p.tile);
 				const int t_next = last ? (tile + stride) * p.tile : t + 1;
 				if (!last || tile + stride < ntiles)
-					load_iq16(xn, p.iq + (size_t)t_next * kN + lane);
+					load_iq16(xn, p.iq + (size_t)t_next * p.hop + lane);
 			}
 #endif
 
@@ -659,7 +659,7 @@ void k1v2_fft_bin(const K1Params p)
 
 	v2f xn[8];
 	if (tile < ntiles)
-		load_iq8(xn, p.iq + (size_t)tile * p.tile * kN + i0);
+		load_iq8(xn, p.iq + (size_t)tile * p.tile * p.hop + i0);
 
 	for (; tile < ntiles; tile += stride) {		/* uniform over the work-group */
 	const int t0 = tile * p.tile;
@@ -695,7 +695,7 @@ void k1v2_fft_bin(const K1Params p)
 				const bool last = (g0 + u + 1 == p.tile);
 				const int t_next = last ? (tile + stride) * p.tile : t + 1;
 				if (!last || tile + stride < ntiles)
-					load_iq8(xn, p.iq + (size_t)t_next * kN + i0);
+					load_iq8(xn, p.iq + (size_t)t_next * p.hop + i0);
 			}
 
 			/* pass 1 (fft.cl:419-420) */

@@ -58,6 +58,15 @@ struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg);
 int fosphor_amd_process_device(struct fosphor *self, const void *d_samples,
                                int n_batches, int batch);
 
+/* Same, with the overlap of the reference's overlap_cc block (lib/overlap_cc_impl.cc:48-79,
+ * include/gnuradio/fosphor/overlap_cc.h:24-32) fused into the read: d_samples is the
+ * UNEXPANDED stream; spectrum t of the call is samples [t*N/overlap, t*N/overlap + N), so
+ * the buffer must hold (n_batches*batch - 1)*N/overlap + N samples.  overlap must divide N;
+ * overlap = 1 is fosphor_amd_process_device.  Results equal processing the stream that
+ * overlap_cc(N, overlap) would have produced. */
+int fosphor_amd_process_device_overlap(struct fosphor *self, const void *d_samples,
+                                       int n_batches, int batch, int overlap);
+
 /* Wait for queued work; counterpart of fosphor_cl_finish (cl.c:970-1061):
  * 1 = new results, 0 = nothing was pending, -EIO = device error. */
 int fosphor_amd_finish(struct fosphor *self);

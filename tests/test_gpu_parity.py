@@ -368,3 +368,37 @@ def test_sharded_batch_equals_single_launch(amd, torch_cuda, oracle_built):
     assert_close(ranks[1].waterfall, o.waterfall, "sharded waterfall (rank 1 rows)")
     for fr in ranks:
         fr.close()
+
+
+def overlap_cc_reference(x, wlen, overlap):
+    """numpy restatement of lib/overlap_cc_impl.cc:64-79: windows of wlen samples whose starts
+    advance wlen/overlap input samples, concatenated."""
+    hop = wlen // overlap
+    n_win = (x.shape[0] - wlen) // hop + 1
+    return np.concatenate([x[i * hop:i * hop + wlen] for i in range(n_win)])
+
+
+@pytest.mark.parametrize("overlap", [2, 4])
+def test_fused_overlap_equals_materialised_stream(amd, torch_cuda, oracle_built, overlap):
+    """N1: reading overlapped windows straight from the unexpanded stream == feeding the sink the
+    stream overlap_cc(1024, overlap) would have produced (BASELINE config C3's 50 % overlap)."""
+    torch = torch_cuda
+    n_spec = 2 * 64
+    hop = 1024 // overlap
+    x = add_tone(gaussian_iq((n_spec - 1) * hop + 1024, 48), 0.1, 0.07)
+    expanded = overlap_cc_reference(x, 1024, overlap)
+    assert expanded.shape[0] == n_spec * 1024
+    f = amd.Fosphor(max_spectra=n_spec)
+    assert f.process_device_overlap(torch.from_numpy(x).cuda(), 2, 64, overlap) == 0
+    o = Oracle()
+    for k in range(2):
+        assert o.process(expanded[k * 64 * 1024:(k + 1) * 64 * 1024]) == 0
+    compare_state(f, o, "fused overlap %d" % overlap)
+    # and against the product's own non-fused path on the materialised stream
+    g = amd.Fosphor(max_spectra=n_spec)
+    assert g.process_device(torch.from_numpy(expanded).cuda(), 2, 64) == 0
+    assert np.array_equal(f.hitcount, g.hitcount)
+    assert np.array_equal(canon_bits(f.waterfall), canon_bits(g.waterfall))
+    assert np.array_equal(canon_bits(f.histogram), canon_bits(g.histogram))
+    assert f.process_device_overlap(torch.from_numpy(x).cuda(), 2, 64, 3) == -errno.EINVAL
+    f.close(); g.close()
