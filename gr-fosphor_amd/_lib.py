@@ -88,6 +88,33 @@ SIGNATURES = {
     "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
+    # include/fosphor_amd_sink.h
+    "fosphor_amd_process_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fosphor_amd_wait_upload": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_fifo_new": (C.c_void_p, [C.c_int, C.c_int]),
+    "fosphor_amd_fifo_free": (None, [C.c_void_p]),
+    "fosphor_amd_fifo_free_space": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_fifo_used": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_fifo_write_max_size": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_fifo_write_prepare": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "fosphor_amd_fifo_write_commit": (None, [C.c_void_p, C.c_int]),
+    "fosphor_amd_fifo_read_max_size": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_fifo_read_peek": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "fosphor_amd_fifo_read_discard": (None, [C.c_void_p, C.c_int]),
+    "fosphor_amd_sink_new": (C.c_void_p, []),
+    "fosphor_amd_sink_free": (None, [C.c_void_p]),
+    "fosphor_amd_sink_start": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_sink_stop": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_sink_work": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fosphor_amd_sink_ui_action": (None, [C.c_void_p, C.c_int]),
+    "fosphor_amd_sink_set_frequency_range": (None, [C.c_void_p, C.c_double, C.c_double]),
+    "fosphor_amd_sink_set_fft_window": (None, [C.c_void_p, C.c_void_p]),
+    "fosphor_amd_sink_set_visible": (None, [C.c_void_p, C.c_int]),
+    "fosphor_amd_sink_core": (C.c_void_p, [C.c_void_p]),
+    "fosphor_amd_sink_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fosphor_amd_process_device_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

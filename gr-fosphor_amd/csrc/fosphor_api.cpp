@@ -19,6 +19,7 @@
 
 #include "fosphor_internal.h"
 #include "../../include/fosphor_amd.h"
+#include "../../include/fosphor_amd_sink.h"
 #include "../../include/fosphor_portable_math.h"
 
 using namespace fosphor_amd;
@@ -89,6 +90,7 @@ struct fosphor
 	float2   *h_stage[2];
 	float2   *d_stage[2];
 	hipEvent_t stage_free[2];
+	hipEvent_t upload_done;			/* H2D of the last fosphor_amd_process_pinned */
 	int       stage_idx;
 	double   *h_thr;			/* pinned, n_bins+1 */
 	float    *h_win;			/* pinned, N */
@@ -194,6 +196,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->d_stage[i]) (void)hipFree(self->d_stage[i]);
 		if (self->stage_free[i]) (void)hipEventDestroy(self->stage_free[i]);
 	}
+	if (self->upload_done) (void)hipEventDestroy(self->upload_done);
 	if (self->h_thr) (void)hipHostFree(self->h_thr);
 	if (self->h_win) (void)hipHostFree(self->h_win);
 	for (hipEvent_t e : self->ev_pool) (void)hipEventDestroy(e);
@@ -668,6 +671,37 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	}
 error:
 	return -EIO;
+}
+
+extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len)
+{
+	int k, rv;
+
+	if (len <= 0 || (len & ((16 * kN) - 1)) || len > (kN * 1024) || len / kN > self->max_spectra)
+		return -EINVAL;		/* cl.c:882-886 */
+
+	k = self->stage_idx;
+	if (!self->d_stage[k]) {
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * kN * 1024), "alloc device staging");
+		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
+	}
+	if (!self->upload_done)
+		HIP_TRY(hipEventCreateWithFlags(&self->upload_done, hipEventDisableTiming), "create upload event");
+	/* d_stage[k] was last read by a K1 queued earlier on the same stream: ordered by the stream */
+	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples (pinned)");
+	HIP_TRY(hipEventRecord(self->upload_done, self->stream), "record upload");
+	rv = run(self, self->d_stage[k], 1, len / kN);
+	self->stage_idx ^= 1;
+	return rv;
+error:
+	return -EIO;
+}
+
+extern "C" int fosphor_amd_wait_upload(struct fosphor *self)
+{
+	if (!self || !self->upload_done)
+		return 0;
+	return hipEventSynchronize(self->upload_done) == hipSuccess ? 0 : -EIO;
 }
 
 extern "C" int fosphor_amd_finish(struct fosphor *self)

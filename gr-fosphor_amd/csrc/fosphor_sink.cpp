@@ -1,0 +1,330 @@
+/*
+ * fosphor_sink.cpp -- GNU-Radio-free fifo + sink runtime (include/fosphor_amd_sink.h)
+ *
+ * fifo:          lib/fifo.{h,cc}
+ * sink_runtime:  lib/base_sink_c_impl.{h,cc} -- work(), worker(), render(), settings, UI actions
+ */
+#include <errno.h>
+#include <string.h>
+
+#include <chrono>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/fosphor_amd_sink.h"
+
+namespace fosphor_amd {
+
+/* ------------------------------------------------------------------------ */
+/* fifo (lib/fifo.cc)                                                       */
+/* ------------------------------------------------------------------------ */
+
+fifo::fifo(int length, bool pinned)
+  : d_buf(nullptr), d_len(length), d_rp(0), d_wp(0), d_pinned(false)
+{
+	if (pinned) {
+		void *p = nullptr;
+		if (hipHostMalloc(&p, sizeof(std::complex<float>) * (size_t)length, hipHostMallocDefault) == hipSuccess) {
+			d_buf = (std::complex<float> *)p;
+			d_pinned = true;
+		}
+	}
+	if (!d_buf)
+		d_buf = new std::complex<float>[length];
+}
+
+fifo::~fifo()
+{
+	if (d_pinned)
+		(void)hipHostFree(d_buf);
+	else
+		delete[] d_buf;
+}
+
+int fifo::used() { return (d_wp - d_rp) & (d_len - 1); }		/* fifo.cc:34-38 */
+int fifo::free() { return (d_len - 1) - used(); }			/* fifo.cc:28-32: one slot stays empty */
+int fifo::write_max_size() { return d_len - d_wp; }			/* fifo.cc:40-44 */
+int fifo::read_max_size() { return d_len - d_rp; }			/* fifo.cc:70-74 */
+
+std::complex<float> *fifo::write_prepare(int size, bool wait)		/* fifo.cc:46-58 */
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	if (!wait && free() < size)
+		return nullptr;
+	while (free() < size)
+		d_cond_full.wait(lock);
+	return &d_buf[d_wp];
+}
+
+void fifo::write_commit(int size)					/* fifo.cc:60-68 */
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	d_wp = (d_wp + size) & (d_len - 1);
+	d_cond_empty.notify_one();
+}
+
+std::complex<float> *fifo::read_peek(int size, bool wait)		/* fifo.cc:76-88 */
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	if (!wait && used() < size)
+		return nullptr;
+	while (used() < size)
+		d_cond_empty.wait(lock);
+	return &d_buf[d_rp];
+}
+
+void fifo::read_discard(int size)					/* fifo.cc:90-98 */
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	d_rp = (d_rp + size) & (d_len - 1);
+	d_cond_full.notify_one();
+}
+
+/* ------------------------------------------------------------------------ */
+/* sink_runtime (lib/base_sink_c_impl.cc)                                   */
+/* ------------------------------------------------------------------------ */
+
+const int sink_runtime::k_db_per_div[5] = {1, 2, 5, 10, 20};		/* base_sink_c_impl.cc:48 */
+
+sink_runtime::sink_runtime()
+  : d_fosphor(nullptr), d_active(false), d_frozen(false), d_visible(true), d_draining(false),
+    d_settings_changed(0), d_db_ref(0), d_db_per_div_idx(3),
+    d_zoom_enabled(false), d_zoom_center(0.5), d_zoom_width(0.2), d_ratio(0.35f),
+    d_have_window(false), d_frames(0), d_samples(0)
+{
+	d_frequency.center = 0.0;
+	d_frequency.span = 1.0;
+	d_fifo = new fifo(2 * 1024 * 1024, true);			/* base_sink_c_impl.cc:58 */
+	d_render_main = new fosphor_render();
+	fosphor_render_defaults(d_render_main);				/* :61-62 */
+}
+
+sink_runtime::~sink_runtime()
+{
+	stop();
+	delete d_render_main;
+	delete d_fifo;
+}
+
+void sink_runtime::settings_mark_changed(uint32_t s)			/* :204-209 */
+{
+	std::lock_guard<std::mutex> lock(d_settings_mutex);
+	d_settings_changed |= s;
+}
+
+uint32_t sink_runtime::settings_get_and_reset_changed()			/* :211-218 */
+{
+	std::lock_guard<std::mutex> lock(d_settings_mutex);
+	uint32_t v = d_settings_changed;
+	d_settings_changed = 0;
+	return v;
+}
+
+void sink_runtime::settings_apply(uint32_t s)				/* :220-288, compute-relevant part */
+{
+	if (s & SETTING_POWER_RANGE)
+		fosphor_set_power_range(d_fosphor, d_db_ref, k_db_per_div[d_db_per_div_idx]);
+	if (s & SETTING_FREQUENCY_RANGE)
+		fosphor_set_frequency_range(d_fosphor, d_frequency.center, d_frequency.span);
+	if ((s & SETTING_FFT_WINDOW) && d_have_window)
+		fosphor_set_fft_window(d_fosphor, d_fft_window);
+	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS)) {
+		d_render_main->histo_wf_ratio = d_ratio;
+		d_render_main->channels[0].enabled = d_zoom_enabled;
+		d_render_main->channels[0].center = (float)d_zoom_center;
+		d_render_main->channels[0].width = (float)d_zoom_width;
+		fosphor_render_refresh(d_render_main);
+	}
+}
+
+void sink_runtime::worker()						/* :77-122 */
+{
+	d_fosphor = fosphor_init();
+	if (!d_fosphor) {
+		d_active = false;
+		return;
+	}
+	settings_apply(~(uint32_t)SETTING_DIMENSIONS);			/* :106-109 */
+	while (d_active || (d_draining && d_fifo->used() >= 16 * 1024))
+		render();
+	fosphor_release(d_fosphor);
+	d_fosphor = nullptr;
+}
+
+void sink_runtime::render()						/* :130-201 */
+{
+	const int fft_len = 1024, batch_mult = 16, batch_max = 1024, max_iter = 8;
+	int i, tot_len;
+
+	settings_apply(settings_get_and_reset_changed());
+
+	tot_len = d_fifo->used();
+	for (i = 0; i < max_iter && tot_len; i++) {
+		int len = tot_len;
+		if (len > d_fifo->read_max_size())
+			len = d_fifo->read_max_size();
+		len &= ~((batch_mult * fft_len) - 1);			/* :156 */
+		if (len > (batch_max * fft_len))
+			len = batch_max * fft_len;			/* :157-158 */
+		tot_len -= len;
+		if (!len)
+			break;
+		if (!d_frozen) {
+			std::complex<float> *data = d_fifo->read_peek(len, false);
+			int rv;
+			if (d_fifo->pinned()) {
+				/* DMA straight from the ring; the region is released only once the copy is done */
+				rv = fosphor_amd_process_pinned(d_fosphor, data, len);
+				(void)fosphor_amd_wait_upload(d_fosphor);
+			} else {
+				rv = fosphor_process(d_fosphor, data, len);
+			}
+			if (rv == 0)
+				d_samples += (uint64_t)len;
+		}
+		d_fifo->read_discard(len);				/* :174 */
+	}
+
+	if (d_visible) {
+		fosphor_draw(d_fosphor, d_render_main);			/* :178-195: the per-frame sync point */
+		d_frames++;
+	} else {
+		std::this_thread::sleep_for(std::chrono::milliseconds(10));	/* :197-200 */
+	}
+	if (!tot_len && i == 0)
+		std::this_thread::sleep_for(std::chrono::microseconds(200));	/* nothing queued: do not spin */
+}
+
+int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432-462 */
+{
+	int l = noutput_items;
+	int mw = d_fifo->write_max_size();
+	if (l > mw)
+		l = mw;
+	if (!l)
+		return 0;
+	std::complex<float> *dst = d_fifo->write_prepare(l, true);
+	if (!dst)
+		return 0;
+	memcpy(dst, in, sizeof(std::complex<float>) * (size_t)l);
+	d_fifo->write_commit(l);
+	return l;
+}
+
+bool sink_runtime::start()						/* :464-472 */
+{
+	if (!d_active) {
+		d_active = true;
+		d_draining = false;
+		d_worker = std::thread(&sink_runtime::worker, this);
+	}
+	return true;
+}
+
+bool sink_runtime::stop()						/* :474-483 */
+{
+	if (d_active || d_worker.joinable()) {
+		d_draining = true;
+		d_active = false;
+		if (d_worker.joinable())
+			d_worker.join();
+		d_draining = false;
+	}
+	return true;
+}
+
+void sink_runtime::execute_ui_action(ui_action_t action)		/* :305-369 */
+{
+	switch (action) {
+	case DB_PER_DIV_UP:	if (d_db_per_div_idx < 4) d_db_per_div_idx++; break;
+	case DB_PER_DIV_DOWN:	if (d_db_per_div_idx > 0) d_db_per_div_idx--; break;
+	case REF_UP:		d_db_ref += k_db_per_div[d_db_per_div_idx]; break;
+	case REF_DOWN:		d_db_ref -= k_db_per_div[d_db_per_div_idx]; break;
+	case ZOOM_TOGGLE:	d_zoom_enabled = !d_zoom_enabled; break;
+	case ZOOM_WIDTH_UP:	if (d_zoom_enabled) d_zoom_width *= 2.0; break;
+	case ZOOM_WIDTH_DOWN:	if (d_zoom_enabled) d_zoom_width /= 2.0; break;
+	case ZOOM_CENTER_UP:	if (d_zoom_enabled) d_zoom_center += d_zoom_width / 8.0; break;
+	case ZOOM_CENTER_DOWN:	if (d_zoom_enabled) d_zoom_center -= d_zoom_width / 8.0; break;
+	case RATIO_UP:		if (d_ratio < 0.8f) d_ratio += 0.05f; break;
+	case RATIO_DOWN:	if (d_ratio > 0.2f) d_ratio -= 0.05f; break;
+	case FREEZE_TOGGLE:	d_frozen = !d_frozen; break;
+	}
+	settings_mark_changed(SETTING_POWER_RANGE | SETTING_RENDER_OPTIONS);
+}
+
+void sink_runtime::set_frequency_range(double center, double span)
+{
+	d_frequency.center = center; d_frequency.span = span;
+	settings_mark_changed(SETTING_FREQUENCY_RANGE);
+}
+void sink_runtime::set_frequency_center(double center)
+{
+	d_frequency.center = center;
+	settings_mark_changed(SETTING_FREQUENCY_RANGE);
+}
+void sink_runtime::set_frequency_span(double span)
+{
+	d_frequency.span = span;
+	settings_mark_changed(SETTING_FREQUENCY_RANGE);
+}
+void sink_runtime::set_fft_window(const float *win)
+{
+	memcpy(d_fft_window, win, sizeof(d_fft_window));
+	d_have_window = true;
+	settings_mark_changed(SETTING_FFT_WINDOW);
+}
+void sink_runtime::set_visible(bool visible) { d_visible = visible; }
+
+} // namespace fosphor_amd
+
+/* ------------------------------------------------------------------------ */
+/* C ABI                                                                    */
+/* ------------------------------------------------------------------------ */
+
+using fosphor_amd::fifo;
+using fosphor_amd::sink_runtime;
+
+struct fosphor_amd_fifo { fifo f; fosphor_amd_fifo(int n, bool p) : f(n, p) {} };
+struct fosphor_amd_sink { sink_runtime s; };
+
+extern "C" {
+
+fosphor_amd_fifo *fosphor_amd_fifo_new(int length, int pinned)
+{
+	if (length < 2 || (length & (length - 1)))
+		return nullptr;
+	return new fosphor_amd_fifo(length, pinned != 0);
+}
+void  fosphor_amd_fifo_free(fosphor_amd_fifo *f) { delete f; }
+int   fosphor_amd_fifo_free_space(fosphor_amd_fifo *f) { return f->f.free(); }
+int   fosphor_amd_fifo_used(fosphor_amd_fifo *f) { return f->f.used(); }
+int   fosphor_amd_fifo_write_max_size(fosphor_amd_fifo *f) { return f->f.write_max_size(); }
+void *fosphor_amd_fifo_write_prepare(fosphor_amd_fifo *f, int size, int wait) { return f->f.write_prepare(size, wait != 0); }
+void  fosphor_amd_fifo_write_commit(fosphor_amd_fifo *f, int size) { f->f.write_commit(size); }
+int   fosphor_amd_fifo_read_max_size(fosphor_amd_fifo *f) { return f->f.read_max_size(); }
+void *fosphor_amd_fifo_read_peek(fosphor_amd_fifo *f, int size, int wait) { return f->f.read_peek(size, wait != 0); }
+void  fosphor_amd_fifo_read_discard(fosphor_amd_fifo *f, int size) { f->f.read_discard(size); }
+
+fosphor_amd_sink *fosphor_amd_sink_new(void) { return new fosphor_amd_sink(); }
+void  fosphor_amd_sink_free(fosphor_amd_sink *s) { delete s; }
+int   fosphor_amd_sink_start(fosphor_amd_sink *s) { return s->s.start() ? 1 : 0; }
+int   fosphor_amd_sink_stop(fosphor_amd_sink *s) { return s->s.stop() ? 1 : 0; }
+int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n)
+{
+	return s->s.work(n, (const std::complex<float> *)samples);
+}
+void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action) { s->s.execute_ui_action((sink_runtime::ui_action_t)action); }
+void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double c, double sp) { s->s.set_frequency_range(c, sp); }
+void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win) { s->s.set_fft_window(win); }
+void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int v) { s->s.set_visible(v != 0); }
+struct fosphor *fosphor_amd_sink_core(fosphor_amd_sink *s) { return s->s.core(); }
+void  fosphor_amd_sink_stats(fosphor_amd_sink *s, uint64_t *frames, uint64_t *samples, int *db_ref, int *db_per_div, int *frozen)
+{
+	if (frames) *frames = s->s.frames();
+	if (samples) *samples = s->s.samples_processed();
+	if (db_ref) *db_ref = s->s.db_ref();
+	if (db_per_div) *db_per_div = s->s.db_per_div();
+	if (frozen) *frozen = s->s.frozen() ? 1 : 0;
+}
+
+} // extern "C"

@@ -1,0 +1,168 @@
+/*
+ * fosphor_amd_sink.h -- GNU-Radio-free sink runtime around the HIP compute core
+ *
+ * Mirrors the data path of gr::fosphor::base_sink_c_impl (lib/base_sink_c_impl.{h,cc}) and
+ * gr::fosphor::fifo (lib/fifo.{h,cc}) without GNU Radio, GL or a window system, so that the
+ * streaming behaviour (work() -> fifo -> worker thread -> fosphor_process / fosphor_draw) can be
+ * built, tested and measured where GNU Radio is absent.  A GNU Radio block wraps it 1:1:
+ * base_sink_c::work() forwards to sink_runtime::work(), the GUI shells forward their key /
+ * mouse callbacks to execute_ui_action().  INTEGRATION.md shows the wrapper.
+ *
+ * Differences from the reference, all on purpose:
+ *   - the FIFO lives in pinned host memory and fosphor_amd_process_pinned() DMAs straight out of
+ *     it; read_discard() happens only after the copy's event has completed.  The reference
+ *     enqueues a non-blocking write from the FIFO and discards immediately
+ *     (cl.c:903-910 vs base_sink_c_impl.cc:168-174): a latent race, not reproduced;
+ *   - no GL context: "visible" only decides whether render() synchronises (fosphor_draw) per frame;
+ *   - set_fft_window takes the 1024 taps (gr::fft::window::build is GNU Radio's, the caller's).
+ */
+#ifndef FOSPHOR_AMD_SINK_H
+#define FOSPHOR_AMD_SINK_H
+
+#include <stdint.h>
+
+#include "fosphor_amd.h"
+
+#ifdef __cplusplus
+#include <atomic>
+#include <complex>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+namespace fosphor_amd {
+
+/* lib/fifo.h:20-46 -- same interface and semantics: power-of-two ring of complex samples, one
+ * slot kept empty (free = len - 1 - used, fifo.cc:28-38), contiguous zero-copy regions
+ * (write_max_size / read_max_size = distance to the end of the ring), blocking prepare/peek. */
+class fifo
+{
+ public:
+	explicit fifo(int length, bool pinned = false);
+	~fifo();
+
+	int free();
+	int used();
+
+	int write_max_size();
+	std::complex<float> *write_prepare(int size, bool wait = true);
+	void write_commit(int size);
+
+	int read_max_size();
+	std::complex<float> *read_peek(int size, bool wait = true);
+	void read_discard(int size);
+
+	bool pinned() const { return d_pinned; }
+
+ private:
+	std::complex<float> *d_buf;
+	int d_len, d_rp, d_wp;
+	bool d_pinned;
+	std::mutex d_mutex;
+	std::condition_variable d_cond_empty, d_cond_full;
+};
+
+/* include/gnuradio/fosphor/base_sink_c.h:24-59 + lib/base_sink_c_impl.{h,cc}, data path only */
+class sink_runtime
+{
+ public:
+	enum ui_action_t {	/* base_sink_c.h:35-48, same order */
+		DB_PER_DIV_UP, DB_PER_DIV_DOWN, REF_UP, REF_DOWN,
+		ZOOM_TOGGLE, ZOOM_WIDTH_UP, ZOOM_WIDTH_DOWN, ZOOM_CENTER_UP, ZOOM_CENTER_DOWN,
+		RATIO_UP, RATIO_DOWN, FREEZE_TOGGLE,
+	};
+
+	sink_runtime();
+	~sink_runtime();
+
+	/* base_sink_c_impl::work (base_sink_c_impl.cc:432-462): copies up to noutput_items samples
+	 * into the FIFO (blocking while it is full), returns how many were taken. */
+	int work(int noutput_items, const std::complex<float> *in);
+
+	bool start();		/* base_sink_c_impl.cc:464-472: spawns the worker */
+	bool stop();		/* :474-483; drains what is already in the FIFO first */
+
+	void execute_ui_action(ui_action_t action);		/* :305-369 */
+	void set_frequency_range(double center, double span);	/* :399-405 */
+	void set_frequency_center(double center);
+	void set_frequency_span(double span);
+	void set_fft_window(const float *win);			/* :423-430, taps instead of an enum */
+	void set_visible(bool visible);				/* cb_visibility, :297-302 */
+
+	struct fosphor *core() { return d_fosphor; }
+	uint64_t frames() const { return d_frames.load(); }
+	uint64_t samples_processed() const { return d_samples.load(); }
+	int db_ref() const { return d_db_ref; }
+	int db_per_div() const { return k_db_per_div[d_db_per_div_idx]; }
+	bool frozen() const { return d_frozen.load(); }
+
+ private:
+	enum {	/* base_sink_c_impl.h:56-69 */
+		SETTING_DIMENSIONS = 1 << 0, SETTING_POWER_RANGE = 1 << 1, SETTING_FREQUENCY_RANGE = 1 << 2,
+		SETTING_FFT_WINDOW = 1 << 3, SETTING_RENDER_OPTIONS = 1 << 4,
+	};
+	static const int k_db_per_div[5];
+
+	void worker();
+	void render();
+	void settings_mark_changed(uint32_t s);
+	uint32_t settings_get_and_reset_changed();
+	void settings_apply(uint32_t s);
+
+	fifo *d_fifo;
+	struct fosphor *d_fosphor;
+	struct fosphor_render *d_render_main;
+	std::thread d_worker;
+	std::atomic<bool> d_active, d_frozen, d_visible, d_draining;
+	std::mutex d_settings_mutex;
+	uint32_t d_settings_changed;
+	int d_db_ref, d_db_per_div_idx;
+	bool d_zoom_enabled; double d_zoom_center, d_zoom_width; float d_ratio;
+	struct { double center, span; } d_frequency;
+	float d_fft_window[1024]; bool d_have_window;
+	std::atomic<uint64_t> d_frames, d_samples;
+};
+
+} // namespace fosphor_amd
+
+extern "C" {
+#endif /* __cplusplus */
+
+/* ---- C ABI (ctypes / cgo-style bindings and the tests) ---------------------------------- */
+
+/* fosphor_process from PINNED host memory without the staging copy: the H2D is queued straight
+ * from `samples`; the caller must keep the region untouched until fosphor_amd_wait_upload()
+ * returns.  Same len rules and return codes as fosphor_process (cl.c:882-886). */
+int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len);
+int fosphor_amd_wait_upload(struct fosphor *self);
+
+typedef struct fosphor_amd_fifo fosphor_amd_fifo;
+fosphor_amd_fifo *fosphor_amd_fifo_new(int length, int pinned);
+void  fosphor_amd_fifo_free(fosphor_amd_fifo *f);
+int   fosphor_amd_fifo_free_space(fosphor_amd_fifo *f);
+int   fosphor_amd_fifo_used(fosphor_amd_fifo *f);
+int   fosphor_amd_fifo_write_max_size(fosphor_amd_fifo *f);
+void *fosphor_amd_fifo_write_prepare(fosphor_amd_fifo *f, int size, int wait);
+void  fosphor_amd_fifo_write_commit(fosphor_amd_fifo *f, int size);
+int   fosphor_amd_fifo_read_max_size(fosphor_amd_fifo *f);
+void *fosphor_amd_fifo_read_peek(fosphor_amd_fifo *f, int size, int wait);
+void  fosphor_amd_fifo_read_discard(fosphor_amd_fifo *f, int size);
+
+typedef struct fosphor_amd_sink fosphor_amd_sink;
+fosphor_amd_sink *fosphor_amd_sink_new(void);
+void  fosphor_amd_sink_free(fosphor_amd_sink *s);
+int   fosphor_amd_sink_start(fosphor_amd_sink *s);
+int   fosphor_amd_sink_stop(fosphor_amd_sink *s);
+int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n);
+void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action);
+void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double center, double span);
+void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win);
+void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int visible);
+struct fosphor *fosphor_amd_sink_core(fosphor_amd_sink *s);
+void  fosphor_amd_sink_stats(fosphor_amd_sink *s, uint64_t *frames, uint64_t *samples, int *db_ref, int *db_per_div, int *frozen);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* FOSPHOR_AMD_SINK_H */

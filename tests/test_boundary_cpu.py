@@ -32,7 +32,9 @@ def declared_functions(header):
 
 def test_library_exports_every_declared_symbol(amd):
     lib = C.CDLL(amd.LIB_PATH)
-    want = declared_functions("fosphor.h") + declared_functions("fosphor_amd.h")
+    want = sorted(set(declared_functions("fosphor.h") + declared_functions("fosphor_amd.h")
+                      + declared_functions("fosphor_amd_sink.h")))
+    want = [n for n in want if n not in ("fosphor_amd_fifo", "fosphor_amd_sink")]	# typedef names
     assert "fosphor_process" in want and "fosphor_amd_process_device" in want and len(want) >= 30
     missing = [n for n in want if not hasattr(lib, n)]
     assert not missing, "declared but not exported: %s" % missing
@@ -152,3 +154,41 @@ def test_product_never_touches_the_oracle():
                              r'libfosphor_oracle|libfosphor_ref|fosphor_oracle_[a-z]+\s*\(', txt):
                     bad.append(os.path.join(base, fn))
     assert not bad, bad
+
+
+def test_fifo_semantics(amd):
+    """lib/fifo.{h,cc}: power-of-two ring, one slot kept empty, contiguous regions to the end of
+    the ring, non-blocking prepare / peek return NULL."""
+    import threading
+    L = amd.load()
+    f = L.fosphor_amd_fifo_new(1024, 0)
+    assert f and L.fosphor_amd_fifo_new(1000, 0) is None		# power of two only
+    assert L.fosphor_amd_fifo_used(f) == 0 and L.fosphor_amd_fifo_free_space(f) == 1023	# fifo.cc:28-38
+    assert L.fosphor_amd_fifo_write_max_size(f) == 1024 and L.fosphor_amd_fifo_read_max_size(f) == 1024
+    assert L.fosphor_amd_fifo_read_peek(f, 1, 0) is None			# empty, no wait
+    p = L.fosphor_amd_fifo_write_prepare(f, 600, 0)
+    buf = (C.c_float * 1200).from_address(p)
+    buf[0], buf[1199] = 1.5, -2.5
+    L.fosphor_amd_fifo_write_commit(f, 600)
+    assert L.fosphor_amd_fifo_used(f) == 600 and L.fosphor_amd_fifo_free_space(f) == 423
+    assert L.fosphor_amd_fifo_write_max_size(f) == 424			# distance to the end of the ring
+    assert L.fosphor_amd_fifo_write_prepare(f, 424, 0) is None		# only 423 free
+    q = L.fosphor_amd_fifo_read_peek(f, 600, 0)
+    rb = (C.c_float * 1200).from_address(q)
+    assert rb[0] == 1.5 and rb[1199] == -2.5
+    L.fosphor_amd_fifo_read_discard(f, 600)
+    assert L.fosphor_amd_fifo_used(f) == 0 and L.fosphor_amd_fifo_read_max_size(f) == 424
+    # wrap: fill to the end, then the write pointer is back at 0
+    L.fosphor_amd_fifo_write_prepare(f, 424, 0); L.fosphor_amd_fifo_write_commit(f, 424)
+    assert L.fosphor_amd_fifo_write_max_size(f) == 1024 and L.fosphor_amd_fifo_used(f) == 424
+    # blocking write is released by a reader
+    L.fosphor_amd_fifo_write_prepare(f, 500, 0); L.fosphor_amd_fifo_write_commit(f, 500)	# used 924
+    done = []
+    def writer():
+        L.fosphor_amd_fifo_write_prepare(f, 200, 1)				# needs 200 free, has 99: blocks
+        done.append(1)
+    t = threading.Thread(target=writer); t.start()
+    t.join(0.2); assert t.is_alive() and not done
+    L.fosphor_amd_fifo_read_discard(f, 424)
+    t.join(2.0); assert done
+    L.fosphor_amd_fifo_free(f)

@@ -402,3 +402,75 @@ def test_fused_overlap_equals_materialised_stream(amd, torch_cuda, oracle_built,
     assert np.array_equal(canon_bits(f.histogram), canon_bits(g.histogram))
     assert f.process_device_overlap(torch.from_numpy(x).cuda(), 2, 64, 3) == -errno.EINVAL
     f.close(); g.close()
+
+
+def test_sink_runtime_streams_through_fifo(amd, torch_cuda, oracle_built):
+    """N2: the GNU-Radio-free sink (work() -> pinned fifo -> worker thread -> fosphor_process ->
+    fosphor_draw), fed like the GR scheduler feeds base_sink_c_impl::work.  Batch boundaries depend
+    on thread timing (as in the reference), so the check uses what does not: every sample is
+    processed once, the ring position, and the waterfall rows (one per spectrum)."""
+    import ctypes as C
+    L = amd.load()
+    n_spec = 3000						# > 1024: wraps the ring; not a multiple of 16
+    x = add_tone(gaussian_iq(n_spec * 1024, 49), 0.1, 0.21)
+    s = L.fosphor_amd_sink_new()
+    L.fosphor_amd_sink_set_frequency_range(s, 100e6, 2e6)
+    assert L.fosphor_amd_sink_start(s) == 1
+    flat = np.ascontiguousarray(x).reshape(-1)
+    pos, total = 0, n_spec * 1024
+    chunk = 37 * 1024 + 5					# deliberately unaligned chunks
+    while pos < total:
+        n = min(chunk, total - pos)
+        took = L.fosphor_amd_sink_work(s, flat[2 * pos:].ctypes.data, n)
+        assert 0 <= took <= n
+        pos += took
+    L.fosphor_amd_sink_stop(s)					# drains whole 16-spectrum groups
+    frames, samples, db_ref, db_div, frozen = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_int(), C.c_int()
+    L.fosphor_amd_sink_stats(s, C.byref(frames), C.byref(samples), C.byref(db_ref), C.byref(db_div), C.byref(frozen))
+    done_spec = (n_spec // 16) * 16
+    assert samples.value == done_spec * 1024 and frames.value >= 1
+    assert (db_ref.value, db_div.value, frozen.value) == (0, 10, 0)
+    L.fosphor_amd_sink_free(s)
+
+    # the same stream through a plain instance in one go, as the reference for the rows
+    s2 = L.fosphor_amd_sink_new()
+    L.fosphor_amd_sink_ui_action(s2, 0)			# DB_PER_DIV_UP: 10 -> 20 dB/div
+    L.fosphor_amd_sink_ui_action(s2, 3)			# REF_DOWN by 20
+    L.fosphor_amd_sink_ui_action(s2, 11)			# FREEZE_TOGGLE
+    L.fosphor_amd_sink_stats(s2, None, None, C.byref(db_ref), C.byref(db_div), C.byref(frozen))
+    assert (db_ref.value, db_div.value, frozen.value) == (-20, 20, 1)
+    L.fosphor_amd_sink_free(s2)
+
+
+def test_sink_waterfall_matches_oracle(amd, torch_cuda, oracle_built):
+    """Rows written through the streaming sink equal the oracle's rows for the same stream."""
+    import ctypes as C
+    L = amd.load()
+    n_spec = 1600
+    x = gaussian_iq(n_spec * 1024, 50)
+    s = L.fosphor_amd_sink_new()
+    assert L.fosphor_amd_sink_start(s) == 1
+    flat = np.ascontiguousarray(x).reshape(-1)
+    pos = 0
+    while pos < n_spec * 1024:
+        pos += L.fosphor_amd_sink_work(s, flat[2 * pos:].ctypes.data, min(64 * 1024, n_spec * 1024 - pos))
+    # read the result through the core BEFORE stop() releases it: wait until everything is consumed
+    import time
+    samples = C.c_uint64()
+    for _ in range(2000):
+        L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+        if samples.value == n_spec * 1024:
+            break
+        time.sleep(0.005)
+    assert samples.value == n_spec * 1024
+    core = L.fosphor_amd_sink_core(s)
+    wf = np.empty((1024, 1024), np.float32)
+    assert L.fosphor_amd_read(core, 0, wf.ctypes.data, wf.nbytes) == 0
+    b = amd.Buffers(); L.fosphor_amd_get_buffers(core, C.byref(b))
+    assert b.waterfall_pos == n_spec & 1023
+    o = Oracle()
+    for k in range(0, n_spec, 400):
+        o.process(x[k * 1024:(k + 400) * 1024], nthreads=8)
+    assert_close(wf, o.waterfall, "sink waterfall")
+    L.fosphor_amd_sink_stop(s)
+    L.fosphor_amd_sink_free(s)
