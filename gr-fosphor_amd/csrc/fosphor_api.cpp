@@ -76,6 +76,8 @@ struct fosphor
 	int       overlap;			/* 1: two-stream pipeline for process paths */
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
+	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
+	int       last_hc16;
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
 	long long *d_dbg;			/* K1_TIMING builds only (FOSPHOR_AMD_K1_TIMING=1) */
@@ -101,6 +103,9 @@ struct fosphor
 	int last_batches;			/* batches in the most recent launch (hitcount view) */
 	int last_slot0;
 	int acc_total;				/* pending accumulate (multi-GPU split) */
+
+	/* the rise/decay table serves batches up to kRiseMax (K3's 16-bit path needs it) */
+	bool rise_ok(int batch) const { return batch <= 8192; }
 
 	/* profiling */
 	int prof;
@@ -185,7 +190,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_set_free[i]) (void)hipEventDestroy(self->ev_set_free[i]);
 	}
 	if (self->stream2) { (void)hipStreamSynchronize(self->stream2); (void)hipStreamDestroy(self->stream2); }
-	(void)hipFree(self->d_hc);
+	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -292,6 +297,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->k1_variant = (e && *e == '1') ? 1 : 2;
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
+	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * kN), "alloc hit count view");
 	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
 	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
 	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk sums");
@@ -474,7 +480,7 @@ static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } re
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
  * d_bins / d_partial; results land in slot `slot0`.. of hc / live_sum / vmax. */
 static int run_count(struct fosphor *self, int n_batches, int batch, int tile, int slot0,
-                     int t_offset, int weight_batch, hipStream_t st)
+                     int t_offset, int weight_batch, hipStream_t st, int use16 = 0)
 {
 	K2Params k2; K2bParams k2b;
 	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
@@ -484,6 +490,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
+	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch)) ? (uint16_t *)self->d_hc : NULL;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
@@ -535,7 +542,7 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 	return 1;
 }
 
-static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st)
+static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0)
 {
 	K3Params k3;
 	const size_t cells = (size_t)self->n_bins * kN;
@@ -546,6 +553,8 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.rise = have_table ? self->d_rise : NULL;
 	k3.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
 	k3.hc = self->d_hc + (size_t)slot0 * cells;
+	k3.hc16 = (use16 && batch <= 1024 && have_table) ? (const uint16_t *)self->d_hc : NULL;
+	k3.hc_export = self->d_hc_export;
 	k3.live_sum = self->d_live_sum + (size_t)slot0 * kN;
 	k3.vmax = self->d_vmax + (size_t)slot0 * kN;
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
@@ -592,14 +601,15 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
 		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
 	}
-	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2))
+	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2, 1))
 		return -EIO;
 	if (self->overlap) {
 		HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
 		self->set_used[set] = 1;
 	}
-	if (run_merge(self, n_batches, batch, 0, st2))
+	if (run_merge(self, n_batches, batch, 0, st2, 1))
 		return -EIO;
+	self->last_hc16 = (batch <= 1024 && batch <= kRiseMax);
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
 	self->last_batches = n_batches;
@@ -736,7 +746,8 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 	out->d_waterfall = self->d_wf;
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
-	out->d_hitcount  = self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * kN;
+	out->d_hitcount  = self->last_hc16 ? self->d_hc_export
+	                   : self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * kN;
 	out->waterfall_pos = self->wf_pos;
 	out->fft_len = kN; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
 	out->histo_scale = self->histo_scale; out->histo_offset = self->histo_offset;
@@ -884,6 +895,7 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 		return -EIO;
 	self->last_batches = 1;
 	self->last_slot0 = self->slot;
+	self->last_hc16 = 0;
 	self->state = ST_PENDING;
 	return 0;
 }

@@ -60,6 +60,7 @@ struct K2Params {
 	const uint32_t *bins;		/* [total/4][N] */
 	const float2   *partial;	/* [total/tile][N] */
 	uint32_t *hc;			/* [n_batches][n_bins][N] */
+	uint16_t *hc16;			/* or (batch <= 1024, one chunk per batch): [n_batches][N/16][n_bins][16] */
 	float    *chunk_sum;		/* [n_chunks][N] */
 	float    *chunk_max;		/* [n_chunks][N] */
 	int   batch;			/* spectra per batch in this launch */
@@ -82,6 +83,8 @@ struct K2bParams {
 /* K3: histogram rise/decay, live EMA, max-hold */
 struct K3Params {
 	const uint32_t *hc;		/* [n_batches][n_bins][N] */
+	const uint16_t *hc16;		/* or slab-major 16-bit counts, see K2Params */
+	uint32_t *hc_export;		/* hc16 path: [n_bins][N] counts of the last batch, for the API view */
 	const float    *live_sum;	/* [n_batches][N] */
 	const float    *vmax;		/* [n_batches][N] */
 	float  *hist;			/* [n_bins][N] */

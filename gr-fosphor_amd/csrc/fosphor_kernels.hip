@@ -942,6 +942,13 @@ void k2_count(const K2Params p)
 		p.chunk_max[(size_t)c * kN + x0 + tid] = m;
 	}
 
+	if (p.hc16) {
+		/* slab-major 16-bit counts: this work-group's [bin][16] block is contiguous (8 KiB at 256 bins) */
+		uint16_t *d16 = p.hc16 + ((size_t)f * (kN / 16) + blockIdx.x) * nb * 16;
+		for (int i = tid; i < nb * 16; i += 256)
+			d16[i] = (uint16_t)h[i];
+		return;
+	}
 	uint32_t *dst = p.hc + (size_t)f * nb * kN + x0 + col;
 	if (cpb == 1) {
 		for (int b = row; b < nb; b += 16)
@@ -997,7 +1004,55 @@ void k3_merge(const K3Params p)
 	const int gid = blockIdx.x * 256 + threadIdx.x;
 	const float fbatch = (float)p.batch;
 
-	if (gid < cells) {
+	if (p.hc16) {
+		/* 16-bit slab-major counts: thread gid = (slab, bin, col) reads 2 B per batch, 8 batches in
+		 * flight; the (d, e) table sits in LDS (one dependent lookup per batch per cell). */
+		__shared__ float2 rise_lds[1025];
+		for (int i = threadIdx.x; i <= p.batch && i < 1025; i += 256)
+			rise_lds[i] = p.rise[i];
+		__syncthreads();
+		if (gid < cells) {
+			const int nb = p.n_bins;
+			const int slab = gid / (nb * 16);
+			const int rem = gid - slab * nb * 16;
+			const int bin = rem >> 4, col = rem & 15;
+			const int hidx = bin * kN + slab * 16 + col;
+			float hv = p.hist[hidx];
+			int f = 0;
+			uint32_t last = 0;
+			for (; f + 8 <= p.n_batches; f += 8) {
+				uint32_t hc[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++)
+					hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(f + u) * cells + gid]);
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
+						const float2 de = rise_lds[hc[u]];
+						hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
+						hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
+						hv = (1.0f < hv) ? 1.0f : hv;
+					}
+				}
+				last = hc[7];
+			}
+			for (; f < p.n_batches; f++) {
+				const uint32_t hc = p.hc16[(size_t)f * cells + gid];
+				if (!((hv <= 0.01f) && (hc == 0))) {
+					const float2 de = rise_lds[hc];
+					hv = (hv - de.x) * de.y + de.x;
+					hv = (hv < 0.0f) ? 0.0f : hv;
+					hv = (1.0f < hv) ? 1.0f : hv;
+				}
+				last = hc;
+			}
+			p.hist[hidx] = hv;
+			p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers) */
+		}
+	}
+	if (p.hc16) {
+		/* cells handled above */
+	} else 	if (gid < cells) {
 		/* one (bin, x) cell; batches applied in order (display.cl:217-254).
 		 * d and e of display.cl:241-245 depend only on the hit count: with a table
 		 * rise[hc] = (d, e) (host-computed with the same powf the oracle uses) the update
@@ -1048,7 +1103,8 @@ void k3_merge(const K3Params p)
 			}
 		}
 		p.hist[gid] = hv;
-	} else if (gid < cells + kN) {
+	}
+	if (gid >= cells && gid < cells + kN) {
 		/* one column: live EMA (display.cl:186-214) and max-hold (display.cl:257-310) */
 		const int x = gid - cells;
 		const int half = kN >> 1;
