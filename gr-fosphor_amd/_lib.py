@@ -87,6 +87,7 @@ SIGNATURES = {
     "fosphor_amd_host_twiddles": (C.c_int, [C.c_void_p]),
     "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
+    "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
     # include/fosphor_amd_sink.h
     "fosphor_amd_process_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

@@ -168,3 +168,7 @@ class Fosphor:
     @property
     def stream(self):
         return self.L.fosphor_amd_stream(self.h)
+
+    @property
+    def stream2(self):
+        return self.L.fosphor_amd_stream2(self.h)

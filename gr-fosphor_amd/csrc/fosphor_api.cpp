@@ -830,18 +830,24 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
                                              int n_local, int t_offset, int total_batch)
 {
 	K1Params k1;
-	int tile, wf_first;
+	int tile, wf_first, set;
+	hipStream_t st2;
 
 	if (!self || !d_samples || n_local < 16 || (n_local & 15) || (t_offset & 15) ||
 	    t_offset < 0 || t_offset + n_local > total_batch || n_local > self->max_spectra)
 		return -EINVAL;
-	if (self->set_used[0] || self->set_used[1]) {
-		/* the split path runs on `stream` only; drain a preceding two-stream launch */
-		(void)hipStreamSynchronize(self->stream2);
-		self->set_used[0] = self->set_used[1] = 0;
-	}
 	if (prepare(self))
 		return -EIO;
+
+	/* same two-stream pipeline as run(): K1 on `stream`, K2 (and later the caller's all-reduce
+	 * and fosphor_amd_merge's K3) on `stream2`, intermediates rotating between two sets */
+	st2 = self->overlap ? self->stream2 : self->stream;
+	set = self->pp;
+	self->pp = (self->pp + 1) % kSets;
+	self->d_bins = self->d_bins_pp[set];
+	self->d_partial = self->d_partial_pp[set];
+	if (self->overlap && self->set_used[set])
+		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
 
 	tile = pick_tile(n_local);
 	/* global spectrum index tau = t_offset + t stores its row iff tau >= total_batch - wf_rows */
@@ -852,8 +858,16 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
 	prof_end(self, self->stream);
 
-	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch, self->stream))
+	if (self->overlap) {
+		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
+		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
+	}
+	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch, st2))
 		return -EIO;
+	if (self->overlap) {
+		HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+		self->set_used[set] = 1;
+	}
 
 	/* the ring advances with the data (host state), so the next frame can be accumulated
 	 * before this one is merged */
@@ -891,7 +905,7 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 		return -EINVAL;
 	if (prepare(self))
 		return -EIO;
-	if (run_merge(self, 1, total_batch, self->slot, self->stream))
+	if (run_merge(self, 1, total_batch, self->slot, self->overlap ? self->stream2 : self->stream))
 		return -EIO;
 	self->last_batches = 1;
 	self->last_slot0 = self->slot;
@@ -987,4 +1001,14 @@ extern "C" int fosphor_amd_set_overlap(struct fosphor *self, int enable)
 	self->overlap = enable ? 1 : 0;
 	self->set_used[0] = self->set_used[1] = 0;
 	return 0;
+}
+
+/* The stream K2 / K3 run on: a second stream when the two-stream pipeline is on, else the main
+ * one.  A multi-GPU caller enqueues its all-reduce of the partial arrays relative to THIS stream
+ * (after fosphor_amd_accumulate_device, before fosphor_amd_merge). */
+extern "C" void *fosphor_amd_stream2(struct fosphor *self)
+{
+	if (!self)
+		return NULL;
+	return (void *)(self->overlap ? self->stream2 : self->stream);
 }

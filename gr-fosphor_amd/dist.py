@@ -76,9 +76,16 @@ class ShardedFosphor:
         import torch
         self.torch = torch
         self.rank, self.world, self.group = rank, world, group
-        # run the library on torch's current stream so the collective is ordered after K2
-        # and K3 after the collective without host synchronisation
-        self.f = fosphor_cls(stream=torch.cuda.current_stream().cuda_stream, **kw)
+        # The library runs on a torch-owned, NON-default stream and every frame is submitted under
+        # it, so the collective (which torch orders after the current stream) follows K2, and K3
+        # follows the collective (work.wait() makes this stream wait) without host synchronisation.
+        # torch's default stream has handle 0, which the C ABI reads as "create a private stream":
+        # that would silently break the ordering, hence the explicit stream.
+        self.stream = torch.cuda.Stream()
+        self.f = fosphor_cls(stream=self.stream.cuda_stream, **kw)
+        # K2 / all-reduce / K3 live on the library's second stream, so that they overlap the
+        # NEXT frame's K1 (VALU-bound) instead of queueing behind it
+        self.stream_b = torch.cuda.ExternalStream(self.f.stream2)
         self.views = []
         for slot in (0, 1):
             self.f.set_partial_slot(slot)
@@ -102,21 +109,26 @@ class ShardedFosphor:
         self.pending = None
 
     def frame(self, d_samples_local, total_batch, overlap=False):
+        torch = self.torch
         off, n = shard_range(total_batch, self.rank, self.world)
         slot = self.k & 1
         self.k += 1
-        self.f.set_partial_slot(slot)
-        rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)
-        if rv:
-            raise RuntimeError("accumulate_device -> %d" % rv)
-        works = allreduce_partials(*self.views[slot], group=self.group, async_op=True)
-        self._retire()			# previous frame: wait for ITS exchange, merge
-        self.pending = (works, slot, total_batch)
-        if not overlap:
-            self._retire()
+        self.stream.wait_stream(torch.cuda.current_stream())	# the caller's producer of d_samples_local
+        with torch.cuda.stream(self.stream):
+            self.f.set_partial_slot(slot)
+            rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)	# K1 here, K2 on stream_b
+            if rv:
+                raise RuntimeError("accumulate_device -> %d" % rv)
+        with torch.cuda.stream(self.stream_b):
+            works = allreduce_partials(*self.views[slot], group=self.group, async_op=True)
+            self._retire()			# previous frame: wait for ITS exchange, merge (K3 on stream_b)
+            self.pending = (works, slot, total_batch)
+            if not overlap:
+                self._retire()
 
     def flush(self):
-        self._retire()
+        with self.torch.cuda.stream(self.stream_b):
+            self._retire()
 
 
 def combine_partials_numpy(parts):

@@ -159,8 +159,10 @@ int fosphor_amd_host_twiddles(float *out);
  * Results are identical; used by the bench to time K1 in isolation. */
 int fosphor_amd_set_overlap(struct fosphor *self, int enable);
 
-/* hipStream_t the instance runs on. */
+/* hipStream_t the instance runs on (K1), and the one K2 / K3 run on (a second stream while the
+ * pipeline is on).  The all-reduce between accumulate and merge must be ordered on the latter. */
 void *fosphor_amd_stream(struct fosphor *self);
+void *fosphor_amd_stream2(struct fosphor *self);
 
 /* Library identification: "fosphor_amd <version> gfx950". */
 const char *fosphor_amd_version(void);

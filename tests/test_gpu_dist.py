@@ -1,0 +1,83 @@
+"""GPU: two ranks of gr_fosphor_amd.dist.ShardedFosphor on ONE device over gloo.
+
+The 8-GPU RCCL run is the driver's; this exercises the same rank code (time-sharded accumulate,
+per-frame all-reduce of hit counts / live sum / max with the previous frame's exchange left in
+flight, merge) with two processes sharing cuda:0 and gloo as transport.  Every rank must end
+with hit counts bit-identical to the oracle's for the whole frame, the same histogram /
+spectrum on both ranks, and rank 1 (last time block) holding the surviving waterfall rows."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["FOSPHOR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FOSPHOR_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from _pkg import gr_fosphor_amd
+from gr_fosphor_amd.dist import ShardedFosphor, shard_range
+from oracle_lib import Oracle, gaussian_iq, add_tone, digest
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+N = 1024
+frames = [2048, 2048, 1024]		# spectra per frame (all ranks together)
+sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, max_spectra=2048)
+o = Oracle()
+t0 = 0
+for k, total in enumerate(frames):
+    x = add_tone(gaussian_iq(total * N, 70 + k), 0.1, 0.11 + 0.02 * k, t0=t0)
+    t0 += total * N
+    off, n = shard_range(total, rank, world)
+    d = torch.from_numpy(x[off * N:(off + n) * N]).cuda()
+    sf.frame(d, total, overlap=True)			# exchange of frame k left in flight
+    assert o.process(x, strict=False, nthreads=4) == 0
+sf.flush()
+f = sf.f
+assert f.finish() >= 0
+assert f.waterfall_pos == o.waterfall_pos
+assert np.array_equal(f.hitcount, o.hitcount.T), "rank %d: hit counts differ from the oracle" % rank
+h, s = f.histogram, f.spectrum
+assert np.allclose(h, o.histogram, rtol=1e-4, atol=2e-6), "rank %d histogram" % rank
+assert np.allclose(s[..., 1], o.spectrum[..., 1], rtol=1e-4, atol=1e-6), "rank %d spectrum" % rank
+# replicated state: both ranks hold the same bits
+mine = torch.tensor([int(digest(h)[:15], 16), int(digest(s)[:15], 16)], dtype=torch.int64)
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(b, both[0]) for b in both), "persistent state differs between ranks"
+if rank == world - 1:		# the last 1024 spectra of the last frame belong to ... both halves: check own rows
+    off, n = shard_range(frames[-1], rank, world)
+    rows = (o.waterfall_pos - frames[-1] + off + np.arange(n)) & 1023
+    assert np.allclose(f.waterfall[rows], o.waterfall[rows], rtol=1e-4, atol=1e-6)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+def test_two_rank_frames_on_one_gpu(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+        assert "rank %d ok" % r in out
