@@ -36,6 +36,7 @@ using namespace fosphor_amd;
 
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
+static const int kMaxN = 8192;
 static const int kSets = 2;		/* intermediate (bin index / partial) sets in rotation */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
@@ -44,11 +45,13 @@ struct fosphor
 {
 	/* geometry / constants */
 	int log2n, n, n_bins, wf_rows;
+	int bins16;				/* bin indices are 16-bit (2 spectra per dword) */
+	int tw_len, tw_off[8];
 	float t0r, t0d, alpha;
 	int max_spectra, max_batches;
 
 	/* reference-visible settings (private.h:44-54) */
-	float fft_win[kN];
+	float fft_win[kMaxN];
 	int   win_dirty;
 	struct { int db_ref, db_per_div; float scale, offset; } power;
 	struct { double center, span; } frequency;
@@ -119,26 +122,33 @@ struct fosphor
 /* ------------------------------------------------------------------------ */
 
 /* Twiddles exactly as the reference forms them (fft.cl:62-68,162-166,286-297), with
- * native_sin/native_cos pinned to fosphor_portable_math.h */
-static void build_twiddles(float2 *tw)
+ * native_sin/native_cos pinned to fosphor_portable_math.h.  Layout: one block per radix-8 pass
+ * with p = 8, 64, 512, ... < N/2 ([k < p][n = 1..7]), then the final radix-2 pass ([k < N/2]).
+ * For N = 1024 this is the kTw2Off / kTw3Off / kTw4Off layout of fosphor_internal.h. */
+static int build_twiddles(float2 *tw, int log2n, int *offsets /* [8] or NULL */)
 {
 	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
-	for (int pass = 0; pass < 2; pass++) {
-		const int p = pass ? 64 : 8;
-		float2 *dst = tw + (pass ? kTw3Off : kTw2Off);
+	const int n = 1 << log2n;
+	int pos = 0, q = 0;
+	for (int p = 8; p < n / 2; p *= 8, q++) {
+		if (offsets) offsets[q] = pos;
 		for (int k = 0; k < p; k++) {
 			const float alpha = -PI_F * (float)k / (float)(4 * p);
-			for (int n = 1; n < 8; n++) {
-				const float arg = (float)n * alpha;
-				dst[k * 7 + (n - 1)] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+			for (int f = 1; f < 8; f++) {
+				const float arg = (float)f * alpha;
+				if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+				pos++;
 			}
 		}
 	}
-	for (int k = 0; k < 512; k++) {
-		const float alpha = -PI_F * (float)k / (float)(512);
+	if (offsets) offsets[q] = pos;
+	for (int k = 0; k < n / 2; k++) {
+		const float alpha = -PI_F * (float)k / (float)(n / 2);
 		const float arg = (float)1 * alpha;
-		tw[kTw4Off + k] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+		if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+		pos++;
 	}
+	return pos;
 }
 
 /* Exact bin thresholds on the double squared magnitude: thr[b] = smallest s >= 0 with
@@ -215,7 +225,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	struct fosphor *self = new (std::nothrow) fosphor();
 	int ndev = 0;
 	size_t tiles_max;
-	std::vector<float2> tw(kTwLen);
+	std::vector<float2> tw;
 
 	if (!self)
 		return NULL;
@@ -231,14 +241,16 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->max_batches = (cfg && cfg->max_batches > 0) ? cfg->max_batches
 	                    : (self->max_spectra / 1024 > 8 ? self->max_spectra / 1024 : 8);
 
-	if (self->log2n != kLog2N) {
-		fprintf(stderr, "[!] fosphor_amd: fft_len_log=%d not supported (only %d)\n", self->log2n, kLog2N);
+	if (self->log2n != 10 && self->log2n != 13) {
+		fprintf(stderr, "[!] fosphor_amd: fft_len_log=%d not supported (10 or 13)\n", self->log2n);
 		goto error;
 	}
-	if (self->n_bins < 16 || self->n_bins > 256 || (self->n_bins & 15)) {
-		fprintf(stderr, "[!] fosphor_amd: n_bins=%d not supported (16..256, multiple of 16)\n", self->n_bins);
+	if (self->n_bins < 16 || self->n_bins > 512 || (self->n_bins & 15)) {
+		fprintf(stderr, "[!] fosphor_amd: n_bins=%d not supported (16..512, multiple of 16)\n", self->n_bins);
 		goto error;
 	}
+	/* 8-bit bin indices (4 spectra per dword) need n_bins <= 256 and the 1024-point kernels */
+	self->bins16 = (self->n_bins > 256) || (self->log2n != 10);
 	if (self->wf_rows & (self->wf_rows - 1)) {
 		fprintf(stderr, "[!] fosphor_amd: wf_rows=%d is not a power of two\n", self->wf_rows);
 		goto error;
@@ -271,15 +283,16 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 
 	tiles_max = (size_t)self->max_spectra / 4;
-	HIP_TRY(hipMalloc((void **)&self->d_win, sizeof(float) * kN), "alloc window");
-	HIP_TRY(hipMalloc((void **)&self->d_tw, sizeof(float2) * kTwLen), "alloc twiddles");
+	HIP_TRY(hipMalloc((void **)&self->d_win, sizeof(float) * self->n), "alloc window");
+	self->tw_len = build_twiddles(NULL, self->log2n, NULL);
+	HIP_TRY(hipMalloc((void **)&self->d_tw, sizeof(float2) * self->tw_len), "alloc twiddles");
 	HIP_TRY(hipMalloc((void **)&self->d_thr, sizeof(double) * (self->n_bins + 1)), "alloc thresholds");
-	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * kN), "alloc waterfall");
-	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * kN), "alloc histogram");
-	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * kN), "alloc spectrum");
+	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * self->n), "alloc waterfall");
+	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
+	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * self->n), "alloc spectrum");
 	for (int i = 0; i < kSets; i++) {
-		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * kN), "alloc bin indices");
-		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * kN), "alloc partials");
+		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * self->n * (self->bins16 ? 2 : 1)), "alloc bin indices");
+		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * self->n), "alloc partials");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], hipEventDisableTiming), "create event");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_set_free[i], hipEventDisableTiming), "create event");
 	}
@@ -296,19 +309,21 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		e = getenv("FOSPHOR_AMD_K1");
 		self->k1_variant = (e && *e == '1') ? 1 : 2;
 	}
-	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * kN), "alloc hit counts");
-	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * kN), "alloc hit count view");
-	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * kN), "alloc live sums");
-	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * kN), "alloc max");
-	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk sums");
-	HIP_TRY(hipMalloc((void **)&self->d_chunk_max, sizeof(float) * (size_t)(self->max_spectra / 16) * kN), "alloc chunk max");
+	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
+	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
+	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * self->n), "alloc live sums");
+	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * self->n), "alloc max");
+	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * self->n), "alloc chunk sums");
+	HIP_TRY(hipMalloc((void **)&self->d_chunk_max, sizeof(float) * (size_t)(self->max_spectra / 16) * self->n), "alloc chunk max");
 	HIP_TRY(hipMalloc((void **)&self->d_rise, sizeof(float2) * (kRiseMax + 1)), "alloc rise table");
 	HIP_TRY(hipHostMalloc((void **)&self->h_rise, sizeof(float2) * (kRiseMax + 1), hipHostMallocDefault), "alloc pinned rise table");
 	HIP_TRY(hipHostMalloc((void **)&self->h_thr, sizeof(double) * (self->n_bins + 1), hipHostMallocDefault), "alloc pinned thr");
-	HIP_TRY(hipHostMalloc((void **)&self->h_win, sizeof(float) * kN, hipHostMallocDefault), "alloc pinned win");
+	HIP_TRY(hipHostMalloc((void **)&self->h_win, sizeof(float) * self->n, hipHostMallocDefault), "alloc pinned win");
 
-	build_twiddles(tw.data());
-	HIP_TRY(hipMemcpy(self->d_tw, tw.data(), sizeof(float2) * kTwLen, hipMemcpyHostToDevice), "upload twiddles");
+	self->tw_len = build_twiddles(NULL, self->log2n, NULL);
+	tw.resize(self->tw_len);
+	build_twiddles(tw.data(), self->log2n, self->tw_off);
+	HIP_TRY(hipMemcpy(self->d_tw, tw.data(), sizeof(float2) * self->tw_len, hipMemcpyHostToDevice), "upload twiddles");
 
 	/* Initial state (fosphor.c:64-66) */
 	fosphor_set_fft_window_default(self);
@@ -333,8 +348,8 @@ extern "C" struct fosphor *fosphor_init(void)
 extern "C" void fosphor_set_fft_window_default(struct fosphor *self)
 {
 	/* periodic Hamming x 1.855, fosphor.c:113-118 */
-	for (int i = 0; i < kN; i++) {
-		float ft = (float)kN;
+	for (int i = 0; i < self->n; i++) {
+		float ft = (float)self->n;
 		float fp = (float)i;
 		self->fft_win[i] = (0.54f - 0.46f * cosf((2.0f * 3.141592f * fp) / ft)) * 1.855f;
 	}
@@ -343,7 +358,7 @@ extern "C" void fosphor_set_fft_window_default(struct fosphor *self)
 
 extern "C" void fosphor_set_fft_window(struct fosphor *self, float *win)
 {
-	memcpy(self->fft_win, win, sizeof(float) * kN);		/* fosphor.c:123-128 */
+	memcpy(self->fft_win, win, sizeof(float) * self->n);		/* fosphor.c:123-128 */
 	self->win_dirty = 1;
 }
 
@@ -352,7 +367,7 @@ extern "C" void fosphor_set_power_range(struct fosphor *self, int db_ref, int db
 	/* fosphor.c:131-152 */
 	int db0 = db_ref - 10 * db_per_div;
 	int db1 = db_ref;
-	float k = fpm_log10f((float)kN);
+	float k = fpm_log10f((float)self->n);
 	float offset = -(k + ((float)db0 / 20.0f));
 	float scale  = 20.0f / (float)(db1 - db0);
 
@@ -404,8 +419,8 @@ static int prepare(struct fosphor *self)
 {
 	if (self->win_dirty) {
 		(void)hipStreamSynchronize(self->stream);	/* h_win may still be in flight */
-		memcpy(self->h_win, self->fft_win, sizeof(float) * kN);
-		HIP_TRY(hipMemcpyAsync(self->d_win, self->h_win, sizeof(float) * kN, hipMemcpyHostToDevice, self->stream), "upload window");
+		memcpy(self->h_win, self->fft_win, sizeof(float) * self->n);
+		HIP_TRY(hipMemcpyAsync(self->d_win, self->h_win, sizeof(float) * self->n, hipMemcpyHostToDevice, self->stream), "upload window");
 		self->win_dirty = 0;
 	}
 	if (self->thr_dirty) {
@@ -416,9 +431,9 @@ static int prepare(struct fosphor *self)
 	}
 	if (self->state == ST_BOOTING) {
 		const float noise_floor = -self->power.offset;
-		HIP_TRY(launch_fill((float *)self->d_spectrum, noise_floor, (size_t)4 * kN, self->stream), "fill spectrum");
-		HIP_TRY(launch_fill(self->d_wf, noise_floor, (size_t)self->wf_rows * kN, self->stream), "fill waterfall");
-		HIP_TRY(launch_fill(self->d_hist, 0.0f, (size_t)self->n_bins * kN, self->stream), "fill histogram");
+		HIP_TRY(launch_fill((float *)self->d_spectrum, noise_floor, (size_t)4 * self->n, self->stream), "fill spectrum");
+		HIP_TRY(launch_fill(self->d_wf, noise_floor, (size_t)self->wf_rows * self->n, self->stream), "fill waterfall");
+		HIP_TRY(launch_fill(self->d_hist, 0.0f, (size_t)self->n_bins * self->n, self->stream), "fill histogram");
 	}
 	return 0;
 error:
@@ -437,7 +452,7 @@ static int pick_tile(int total)
 }
 
 static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int total, int tile,
-                    int wf_pos0, int wf_first, int hop = kN)
+                    int wf_pos0, int wf_first, int hop = 0)
 {
 	const double A = (double)self->histo_scale * 0.150514997831990597606869447362;
 	const double C = (double)self->histo_scale * (double)self->histo_offset;
@@ -452,7 +467,9 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 
 	memset(k1, 0, sizeof(*k1));
 	k1->iq = (const float2 *)d_iq;
-	k1->hop = hop;
+	k1->hop = hop ? hop : self->n;
+	k1->n = self->n; k1->log2n = self->log2n; k1->bins16 = self->bins16;
+	for (int q = 0; q < 8; q++) k1->tw_off[q] = self->tw_off[q];
 	k1->win = self->d_win;
 	k1->tw = self->d_tw;
 	k1->thr = self->d_thr;
@@ -472,7 +489,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->amb = 0.5f - delta0;
 	k1->kappa = kappa;
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
-	k1->variant = self->k1_variant;
+	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : 3;
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -485,19 +502,20 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	K2Params k2; K2bParams k2b;
 	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
 	const int cpb = batch / chunk;
-	const size_t cells = (size_t)self->n_bins * kN;
+	const size_t cells = (size_t)self->n_bins * self->n;
 
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
 	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch)) ? (uint16_t *)self->d_hc : NULL;
+	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
 	if (cpb == 1) {
-		k2.chunk_sum = self->d_live_sum + (size_t)slot0 * kN;
-		k2.chunk_max = self->d_vmax + (size_t)slot0 * kN;
+		k2.chunk_sum = self->d_live_sum + (size_t)slot0 * self->n;
+		k2.chunk_max = self->d_vmax + (size_t)slot0 * self->n;
 	} else {
 		k2.chunk_sum = self->d_chunk_sum;
 		k2.chunk_max = self->d_chunk_max;
@@ -507,9 +525,9 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	HIP_TRY(launch_k2(k2, n_batches * cpb, st), "launch count");
 	if (cpb > 1) {
 		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
-		k2b.live_sum = self->d_live_sum + (size_t)slot0 * kN;
-		k2b.vmax = self->d_vmax + (size_t)slot0 * kN;
-		k2b.n_batches = n_batches; k2b.cpb = cpb;
+		k2b.live_sum = self->d_live_sum + (size_t)slot0 * self->n;
+		k2b.vmax = self->d_vmax + (size_t)slot0 * self->n;
+		k2b.n_batches = n_batches; k2b.cpb = cpb; k2b.n = self->n;
 		HIP_TRY(launch_k2b(k2b, st), "launch chunk reduce");
 	}
 	prof_end(self, st);
@@ -545,7 +563,7 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0)
 {
 	K3Params k3;
-	const size_t cells = (size_t)self->n_bins * kN;
+	const size_t cells = (size_t)self->n_bins * self->n;
 	const int have_table = ensure_rise_table(self, batch, st);
 	if (have_table < 0)
 		return -EIO;
@@ -555,10 +573,10 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.hc = self->d_hc + (size_t)slot0 * cells;
 	k3.hc16 = (use16 && batch <= 1024 && have_table) ? (const uint16_t *)self->d_hc : NULL;
 	k3.hc_export = self->d_hc_export;
-	k3.live_sum = self->d_live_sum + (size_t)slot0 * kN;
-	k3.vmax = self->d_vmax + (size_t)slot0 * kN;
+	k3.live_sum = self->d_live_sum + (size_t)slot0 * self->n;
+	k3.vmax = self->d_vmax + (size_t)slot0 * self->n;
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
-	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins;
+	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins; k3.n = self->n;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
 	prof_begin(self, 2, st);
 	HIP_TRY(launch_k3(k3, st), "launch merge");
@@ -568,7 +586,7 @@ error:
 	return -EIO;
 }
 
-static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch, int hop = kN)
+static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch, int hop = 0)
 {
 	const int total = n_batches * batch;
 	const int tile = pick_tile(total);
@@ -638,11 +656,11 @@ extern "C" int fosphor_amd_process_device_overlap(struct fosphor *self, const vo
 {
 	if (!self || !d_samples || n_batches < 1 || batch < 16 || (batch & 15))
 		return -EINVAL;
-	if (overlap < 1 || overlap > kN || (kN % overlap))
+	if (overlap < 1 || overlap > self->n || (self->n % overlap))
 		return -EINVAL;
 	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
 		return -EINVAL;
-	return run(self, d_samples, n_batches, batch, kN / overlap);
+	return run(self, d_samples, n_batches, batch, self->n / overlap);
 }
 
 extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
@@ -650,11 +668,11 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	int k;
 
 	/* cl.c:882-886 */
-	if (len <= 0 || (len & ((16 * kN) - 1)))
+	if (len <= 0 || (len & ((16 * self->n) - 1)))
 		return -EINVAL;
-	if (len > (kN * 1024))
+	if (len > (self->n * 1024))
 		return -EINVAL;
-	if (len / kN > self->max_spectra)
+	if (len / self->n > self->max_spectra)
 		return -EINVAL;
 
 	/* cl.c:903-910 enqueues a non-blocking write straight from the caller's memory, which the
@@ -663,8 +681,8 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	 * its H2D copy has completed. */
 	k = self->stage_idx;
 	if (!self->h_stage[k]) {
-		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sizeof(float2) * kN * 1024, hipHostMallocDefault), "alloc pinned staging");
-		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * kN * 1024), "alloc device staging");
+		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sizeof(float2) * self->n * 1024, hipHostMallocDefault), "alloc pinned staging");
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * self->n * 1024), "alloc device staging");
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	} else {
 		HIP_TRY(hipEventSynchronize(self->stage_free[k]), "wait staging slot");
@@ -672,7 +690,7 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	memcpy(self->h_stage[k], samples, sizeof(float2) * (size_t)len);
 	HIP_TRY(hipMemcpyAsync(self->d_stage[k], self->h_stage[k], sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples");
 	{
-		int rv = run(self, self->d_stage[k], 1, len / kN);
+		int rv = run(self, self->d_stage[k], 1, len / self->n);
 		/* the slot is free again once everything queued so far (copy + kernels reading
 		 * d_stage[k]) has finished */
 		(void)hipEventRecord(self->stage_free[k], self->stream);
@@ -687,12 +705,12 @@ extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samp
 {
 	int k, rv;
 
-	if (len <= 0 || (len & ((16 * kN) - 1)) || len > (kN * 1024) || len / kN > self->max_spectra)
+	if (len <= 0 || (len & ((16 * self->n) - 1)) || len > (self->n * 1024) || len / self->n > self->max_spectra)
 		return -EINVAL;		/* cl.c:882-886 */
 
 	k = self->stage_idx;
 	if (!self->d_stage[k]) {
-		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * kN * 1024), "alloc device staging");
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * self->n * 1024), "alloc device staging");
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	}
 	if (!self->upload_done)
@@ -700,7 +718,7 @@ extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samp
 	/* d_stage[k] was last read by a K1 queued earlier on the same stream: ordered by the stream */
 	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples (pinned)");
 	HIP_TRY(hipEventRecord(self->upload_done, self->stream), "record upload");
-	rv = run(self, self->d_stage[k], 1, len / kN);
+	rv = run(self, self->d_stage[k], 1, len / self->n);
 	self->stage_idx ^= 1;
 	return rv;
 error:
@@ -747,9 +765,9 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
 	out->d_hitcount  = self->last_hc16 ? self->d_hc_export
-	                   : self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * kN;
+	                   : self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * self->n;
 	out->waterfall_pos = self->wf_pos;
-	out->fft_len = kN; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
+	out->fft_len = self->n; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
 	out->histo_scale = self->histo_scale; out->histo_offset = self->histo_offset;
 	return 0;
 }
@@ -767,10 +785,10 @@ extern "C" int fosphor_amd_read(struct fosphor *self, int which, void *host, uin
 		return rv;
 	fosphor_amd_get_buffers(self, &b);
 	switch (which) {
-	case 0: src = b.d_waterfall; want = sizeof(float) * (uint64_t)self->wf_rows * kN; break;
-	case 1: src = b.d_histogram; want = sizeof(float) * (uint64_t)self->n_bins * kN; break;
-	case 2: src = b.d_spectrum;  want = sizeof(float) * 4 * kN; break;
-	case 3: src = b.d_hitcount;  want = sizeof(uint32_t) * (uint64_t)self->n_bins * kN; break;
+	case 0: src = b.d_waterfall; want = sizeof(float) * (uint64_t)self->wf_rows * self->n; break;
+	case 1: src = b.d_histogram; want = sizeof(float) * (uint64_t)self->n_bins * self->n; break;
+	case 2: src = b.d_spectrum;  want = sizeof(float) * 4 * self->n; break;
+	case 3: src = b.d_hitcount;  want = sizeof(uint32_t) * (uint64_t)self->n_bins * self->n; break;
 	default: return -EINVAL;
 	}
 	if (bytes != want)
@@ -891,11 +909,11 @@ extern "C" int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd
 {
 	if (!self || !out)
 		return -EINVAL;
-	out->d_hc = self->d_hc + (size_t)self->slot * self->n_bins * kN;
-	out->d_live_sum = self->d_live_sum + (size_t)self->slot * kN;
-	out->d_max = self->d_vmax + (size_t)self->slot * kN;
-	out->n_hc = self->n_bins * kN;
-	out->n_cols = kN;
+	out->d_hc = self->d_hc + (size_t)self->slot * self->n_bins * self->n;
+	out->d_live_sum = self->d_live_sum + (size_t)self->slot * self->n;
+	out->d_max = self->d_vmax + (size_t)self->slot * self->n;
+	out->n_hc = self->n_bins * self->n;
+	out->n_cols = self->n;
 	return 0;
 }
 
@@ -970,13 +988,14 @@ extern "C" int fosphor_amd_host_thresholds(int n_bins, float histo_scale, float 
 	return 0;
 }
 
-extern "C" int fosphor_amd_host_twiddle_count(void) { return kTwLen; }
+
+extern "C" int fosphor_amd_host_twiddle_count(void) { return build_twiddles(NULL, 10, NULL); }
 
 extern "C" int fosphor_amd_host_twiddles(float *out)
 {
 	if (!out)
 		return -EINVAL;
-	build_twiddles((float2 *)out);
+	build_twiddles((float2 *)out, 10, NULL);
 	return 0;
 }
 

@@ -30,6 +30,9 @@ constexpr int kK1V2MaxBlocks = 2048;	/* v2: 256 CUs x 8 resident work-groups of 
 struct K1Params {
 	const float2 *iq;		/* spectrum t = iq[t*hop .. t*hop + N) */
 	int   hop;			/* samples between spectrum starts: N, or N/overlap (overlap_cc_impl.cc:74-76) */
+	int   n, log2n;			/* FFT length */
+	int   bins16;			/* 16-bit bin indices, 2 spectra per dword (general kernel) */
+	int   tw_off[8];		/* twiddle block offsets: radix-8 passes p = 8, 64, ...; then the radix-2 pass */
 	const float  *win;		/* [N] */
 	const float2 *tw;		/* [kTwLen] */
 	const double *thr;		/* [n_bins + 1] exact squared-magnitude thresholds */
@@ -47,7 +50,7 @@ struct K1Params {
 	float amb;			/* confident when |v - rint(v)| + kappa |l2| <= amb */
 	float kappa;			/* v_log_f32 error bound per unit of |log2 s|, through the slope binA */
 	float w;			/* 1 - alpha */
-	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum */
+	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum; 3: general N (N/8 threads per spectrum) */
 };
 
 /* K2: bin indices -> hit counts + live sum / max per column.
@@ -63,6 +66,8 @@ struct K2Params {
 	uint16_t *hc16;			/* or (batch <= 1024, one chunk per batch): [n_batches][N/16][n_bins][16] */
 	float    *chunk_sum;		/* [n_chunks][N] */
 	float    *chunk_max;		/* [n_chunks][N] */
+	int   n;			/* FFT length (columns) */
+	int   bins16;			/* bin indices are 16-bit, 2 spectra per dword */
 	int   batch;			/* spectra per batch in this launch */
 	int   chunk;			/* spectra per chunk; divides batch */
 	int   tile;
@@ -77,7 +82,7 @@ struct K2Params {
 struct K2bParams {
 	const float *chunk_sum, *chunk_max;	/* [n_batches * cpb][N] */
 	float *live_sum, *vmax;			/* [n_batches][N] */
-	int   n_batches, cpb;
+	int   n_batches, cpb, n;
 };
 
 /* K3: histogram rise/decay, live EMA, max-hold */
@@ -90,7 +95,7 @@ struct K3Params {
 	float  *hist;			/* [n_bins][N] */
 	float2 *spectrum;		/* [2][N] */
 	const float2 *rise;		/* [batch+1] (d, e) per hit count, or nullptr -> computed in-kernel */
-	int   n_batches, batch, n_bins;
+	int   n_batches, batch, n_bins, n;
 	float t0r, t0d, alpha;
 	float live_decay;		/* (1-alpha)^batch */
 };

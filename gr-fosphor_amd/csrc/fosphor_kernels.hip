@@ -815,9 +815,180 @@ void k1v2_fft_bin(const K1Params p)
 	}	/* tile loop */
 }
 
+/* ------------------------------------------------------------------------ */
+/* K1 general N: N/8 threads per spectrum                                    */
+/* ------------------------------------------------------------------------ */
+/* The reference's plan for any N = 8^k * 2 (fft.cl:397-466 is the N = 1024 instance): k radix-8
+ * Stockham passes with p = 1, 8, 64, ... and a final radix-2 pass with p = N/2, N/8 work-items
+ * of 8 points each.  One work-group of N/8 threads per spectrum (1024 threads for N = 8192),
+ * the N-point exchange slab in dynamic LDS (64 KiB at 8192), twiddles and window read from
+ * global memory (L2-resident tables; this path is a parity case, not the tuned one).
+ * Same swizzle phys(e) = e ^ ((e >> 3) & 15): the store patterns of every pass and the
+ * lane-contiguous reads stay bank-conflict free for any N (the argument of DESIGN.md only
+ * involves address bits 0..6).  Bin indices are 16-bit, 2 spectra per dword. */
+static __device__ __forceinline__ int swz(int e) { return e ^ ((e >> 3) & 15); }
+
+template <int LOG2N, bool WRITE_FFT>
+__global__ __launch_bounds__((1 << LOG2N) / 8)
+void k1big_fft_bin(const K1Params p)
+{
+	constexpr int N = 1 << LOG2N, T = N / 8, NP8 = LOG2N / 3;
+	static_assert(LOG2N % 3 == 1, "plan: radix-8 passes then one radix-2 pass");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	v2f *buf = reinterpret_cast<v2f *>(smem_raw);
+
+	const int i = threadIdx.x;
+	const int ntiles = p.total / p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	const int t0 = tile * p.tile;
+	float live[8], vmax[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++) { live[q] = 0.0f; vmax[q] = vmax_init; }
+
+	for (int g0 = 0; g0 < p.tile; g0 += 2) {
+		uint32_t pack[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) pack[q] = 0;
+
+#pragma unroll 1
+		for (int u = 0; u < 2; u++) {
+			const int t = t0 + g0 + u;
+			const float2 *src = p.iq + (size_t)t * p.hop;
+			v2f r[8];
+
+			/* window (fft.cl:415-417) */
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const v2f xv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + i + T * j));
+				const float wv = p.win[i + T * j];
+				r[j] = v2f{ xv.x * wv, xv.y * wv };
+			}
+
+			/* radix-8 passes p = 1, 8, 64, ... (fft.cl:278-350) */
+			int pp = 1;
+#pragma unroll
+			for (int q8 = 0; q8 < NP8; q8++) {
+				const int k = i & (pp - 1);
+				if (q8 > 0) {
+					const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
+#pragma unroll
+					for (int j = 1; j < 8; j++)
+						r[j] = c_mul(r[j], tw[j - 1]);
+				}
+				dft8(r, s12);
+				const int j0 = ((i - k) << 3) + k;
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					buf[swz(j0 + jj * pp)] = r[R8_PERM(jj)];
+				__syncthreads();
+				if (q8 + 1 < NP8) {
+#pragma unroll
+					for (int j = 0; j < 8; j++)
+						r[j] = buf[swz(i + T * j)];
+					__syncthreads();
+				}
+				pp <<= 3;
+			}
+
+			/* final radix-2 pass, p = N/2 (fft.cl:428-458): butterflies jb = i + T c on (jb, jb + N/2) */
+			v2f x[8];
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int jb = i + T * c;
+				v2f a = buf[swz(jb)];
+				v2f b = buf[swz(jb + N / 2)];
+				b = c_mul(b, twg[p.tw_off[NP8 - 1] + jb]);
+				DFT2(a, b);
+				x[c] = a;		/* column jb */
+				x[c + 4] = b;		/* column jb + N/2 */
+			}
+			__syncthreads();		/* slab free for the next spectrum */
+
+			if (WRITE_FFT) {
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + i + T * c] = x[c];
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + i + T * c + N / 2] = x[c + 4];
+				}
+			}
+
+			/* epilogue (display.cl:136,161-168), as in the 1024-point kernels, 16-bit bin indices */
+			float l2[8];
+			uint32_t bn[8];
+			uint32_t amb = 0;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint32_t ab;
+				const float rr = bin_fast(x[q].x, x[q].y, bk, &l2[q], &ab);
+				amb = amb > ab ? amb : ab;
+				bn[q] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
+			}
+			if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const float v = __builtin_fmaf(bk.A, l2[q], bk.C);
+					const float rr = __builtin_rintf(v);
+					const float a = __builtin_fmaf(__builtin_fabsf(l2[q]), bk.kappa, __builtin_fabsf(v - rr));
+					if (!(a <= bk.amb)) {
+						float nl2;
+						bn[q] = bin_exact(x[q].x, x[q].y, l2[q], (int)bn[q], bk.thr, bk.nb, &nl2);
+						l2[q] = nl2;
+					}
+				}
+			}
+			const bool store_row = (t >= p.wf_first);
+			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * N + i;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const int col_off = T * (q & 3) + (N / 2) * (q >> 2);
+				pack[q] |= bn[q] << (16 * u);
+				live[q] = __builtin_fmaf(live[q], p.w, l2[q]);
+				vmax[q] = max_f32(vmax[q], l2[q]);
+				if (store_row)
+					wf_row[col_off] = l2[q] * F_HALF_LOG10_2;
+			}
+		}
+		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 1) * N + i;
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			dst[T * (q & 3) + (N / 2) * (q >> 2)] = pack[q];
+	}
+	float2 *pp2 = p.partial + (size_t)tile * N + i;
+#pragma unroll
+	for (int q = 0; q < 8; q++)
+		pp2[T * (q & 3) + (N / 2) * (q >> 2)] = make_float2(live[q] * F_HALF_LOG10_2,
+			(vmax[q] == vmax_init) ? -1000.0f : vmax[q] * F_HALF_LOG10_2);
+	}
+}
+
 hipError_t launch_k1(const K1Params &p, hipStream_t s)
 {
 	const int tiles = p.total / p.tile;
+	if (p.variant == 3) {
+		if (p.log2n != 13)
+			return hipErrorInvalidValue;
+		constexpr int N = 8192;
+		int blocks = tiles < 512 ? tiles : 512;		/* 2 work-groups of 64 KiB LDS per CU */
+		static bool attr_set = false;
+		if (!attr_set) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
+			                          hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, true>),
+			                          hipFuncAttributeMaxDynamicSharedMemorySize, N * 8);
+			attr_set = true;
+		}
+		if (p.fft_out)
+			hipLaunchKernelGGL((k1big_fft_bin<13, true>), dim3(blocks), dim3(N / 8), N * 8, s, p);
+		else
+			hipLaunchKernelGGL((k1big_fft_bin<13, false>), dim3(blocks), dim3(N / 8), N * 8, s, p);
+		return hipGetLastError();
+	}
 	if (p.variant == 2) {
 		const int maxb = 256 * 2 * K1V2_WAVES_PER_SIMD;	/* resident 2-wave work-groups on 256 CUs */
 		int blocks = tiles < maxb ? tiles : maxb;
@@ -872,7 +1043,7 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
 __global__ __launch_bounds__(256)
 void k2_count(const K2Params p)
 {
-	__shared__ uint32_t h[256 * 16];		/* [bin][col], display.cl:96,176 */
+	extern __shared__ uint32_t h[];			/* [n_bins][16]: bin-major as display.cl:96,176 */
 	__shared__ float red_s[16][17], red_m[16][17];
 
 	const int tid  = threadIdx.x;
@@ -889,15 +1060,24 @@ void k2_count(const K2Params p)
 		h[i] = 0;
 	__syncthreads();
 
-	/* bins: one dword = 4 consecutive spectra of one column */
-	const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * kN + x0 + col;
-	const int nq = p.chunk >> 2;
+	/* bins: one dword = 4 consecutive spectra of one column (8-bit indices), or 2 (16-bit
+	 * indices, n_bins > 256) */
+	if (p.bins16) {
+		const uint32_t *src16 = p.bins + (size_t)c * (p.chunk >> 1) * p.n + x0 + col;
+		for (int q = row; q < (p.chunk >> 1); q += 16) {
+			const uint32_t v = src16[(size_t)q * p.n];
+			atomicAdd(&h[(v & 0xffffu) * 16 + col], 1u);
+			atomicAdd(&h[(v >> 16) * 16 + col], 1u);
+		}
+	}
+	const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * p.n + x0 + col;
+	const int nq = p.bins16 ? 0 : (p.chunk >> 2);
 	int q = row;
 	for (; q + 48 < nq; q += 64) {			/* 4 independent loads in flight per thread */
 		uint32_t v[4];
 #pragma unroll
 		for (int u = 0; u < 4; u++)
-			v[u] = src[(size_t)(q + 16 * u) * kN];
+			v[u] = src[(size_t)(q + 16 * u) * p.n];
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			atomicAdd(&h[((v[u]      ) & 0xff) * 16 + col], 1u);
@@ -907,7 +1087,7 @@ void k2_count(const K2Params p)
 		}
 	}
 	for (; q < nq; q += 16) {
-		const uint32_t v = src[(size_t)q * kN];
+		const uint32_t v = src[(size_t)q * p.n];
 		atomicAdd(&h[((v      ) & 0xff) * 16 + col], 1u);
 		atomicAdd(&h[((v >>  8) & 0xff) * 16 + col], 1u);
 		atomicAdd(&h[((v >> 16) & 0xff) * 16 + col], 1u);
@@ -918,10 +1098,10 @@ void k2_count(const K2Params p)
 	 * sum_{t in tile} pwr_t (1-a)^(t_last - t) (display.cl:149-150) */
 	{
 		const int tiles = p.chunk / p.tile;
-		const float2 *pp = p.partial + (size_t)c * tiles * kN + x0 + col;
+		const float2 *pp = p.partial + (size_t)c * tiles * p.n + x0 + col;
 		float s = 0.0f, m = -1000.0f;
 		for (int j = row; j < tiles; j += 16) {
-			const float2 v = pp[(size_t)j * kN];
+			const float2 v = pp[(size_t)j * p.n];
 			const int t_last = p.t_offset + t_in + (j + 1) * p.tile - 1;
 			/* (1-a)^k as exp2(k log2(1-a)): relative error ~1e-6 where the weight is not negligible */
 			s += v.x * __builtin_amdgcn_exp2f(p.log2_w * (float)(p.weight_batch - 1 - t_last));
@@ -938,33 +1118,33 @@ void k2_count(const K2Params p)
 			s += red_s[j][tid];
 			m = (m < red_m[j][tid]) ? red_m[j][tid] : m;
 		}
-		p.chunk_sum[(size_t)c * kN + x0 + tid] = s;
-		p.chunk_max[(size_t)c * kN + x0 + tid] = m;
+		p.chunk_sum[(size_t)c * p.n + x0 + tid] = s;
+		p.chunk_max[(size_t)c * p.n + x0 + tid] = m;
 	}
 
 	if (p.hc16) {
 		/* slab-major 16-bit counts: this work-group's [bin][16] block is contiguous (8 KiB at 256 bins) */
-		uint16_t *d16 = p.hc16 + ((size_t)f * (kN / 16) + blockIdx.x) * nb * 16;
+		uint16_t *d16 = p.hc16 + ((size_t)f * ((p.n / 16)) + blockIdx.x) * nb * 16;
 		for (int i = tid; i < nb * 16; i += 256)
 			d16[i] = (uint16_t)h[i];
 		return;
 	}
-	uint32_t *dst = p.hc + (size_t)f * nb * kN + x0 + col;
+	uint32_t *dst = p.hc + (size_t)f * nb * p.n + x0 + col;
 	if (cpb == 1) {
 		for (int b = row; b < nb; b += 16)
-			dst[(size_t)b * kN] = h[b * 16 + col];
+			dst[(size_t)b * p.n] = h[b * 16 + col];
 	} else {
 		for (int b = row; b < nb; b += 16) {
 			const uint32_t v = h[b * 16 + col];
 			if (v)
-				atomicAdd(&dst[(size_t)b * kN], v);
+				atomicAdd(&dst[(size_t)b * p.n], v);
 		}
 	}
 }
 
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
-	hipLaunchKernelGGL(k2_count, dim3(kN / 16, n_chunks), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k2_count, dim3((p.n / 16), n_chunks), dim3(256), (size_t)p.n_bins * 16 * sizeof(uint32_t), s, p);
 	return hipGetLastError();
 }
 
@@ -973,12 +1153,12 @@ __global__ __launch_bounds__(256)
 void k2b_reduce(const K2bParams p)
 {
 	const int gid = blockIdx.x * 256 + threadIdx.x;
-	if (gid >= p.n_batches * kN)
+	if (gid >= p.n_batches * p.n)
 		return;
-	const int f = gid / kN, x = gid - f * kN;
+	const int f = gid / p.n, x = gid - f * p.n;
 	float s = 0.0f, m = -1000.0f;
 	for (int c = 0; c < p.cpb; c++) {
-		const size_t i = (size_t)(f * p.cpb + c) * kN + x;
+		const size_t i = (size_t)(f * p.cpb + c) * p.n + x;
 		s += p.chunk_sum[i];
 		m = (m < p.chunk_max[i]) ? p.chunk_max[i] : m;
 	}
@@ -988,7 +1168,7 @@ void k2b_reduce(const K2bParams p)
 
 hipError_t launch_k2b(const K2bParams &p, hipStream_t s)
 {
-	const int threads = p.n_batches * kN;
+	const int threads = p.n_batches * p.n;
 	hipLaunchKernelGGL(k2b_reduce, dim3((threads + 255) / 256), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
@@ -1000,7 +1180,7 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s)
 __global__ __launch_bounds__(256)
 void k3_merge(const K3Params p)
 {
-	const int cells = p.n_bins * kN;
+	const int cells = p.n_bins * p.n;
 	const int gid = blockIdx.x * 256 + threadIdx.x;
 	const float fbatch = (float)p.batch;
 
@@ -1016,7 +1196,7 @@ void k3_merge(const K3Params p)
 			const int slab = gid / (nb * 16);
 			const int rem = gid - slab * nb * 16;
 			const int bin = rem >> 4, col = rem & 15;
-			const int hidx = bin * kN + slab * 16 + col;
+			const int hidx = bin * p.n + slab * 16 + col;
 			float hv = p.hist[hidx];
 			int f = 0;
 			uint32_t last = 0;
@@ -1104,17 +1284,17 @@ void k3_merge(const K3Params p)
 		}
 		p.hist[gid] = hv;
 	}
-	if (gid >= cells && gid < cells + kN) {
+	if (gid >= cells && gid < cells + p.n) {
 		/* one column: live EMA (display.cl:186-214) and max-hold (display.cl:257-310) */
 		const int x = gid - cells;
-		const int half = kN >> 1;
+		const int half = p.n >> 1;
 		const int i = x ^ half;
 		const float decay = p.live_decay;
 		float live = p.spectrum[i].y;
-		float mh   = p.spectrum[kN + i].y;
+		float mh   = p.spectrum[p.n + i].y;
 		for (int f = 0; f < p.n_batches; f++) {
-			const float sum = p.live_sum[(size_t)f * kN + x];
-			const float mx  = p.vmax[(size_t)f * kN + x];
+			const float sum = p.live_sum[(size_t)f * p.n + x];
+			const float mx  = p.vmax[(size_t)f * p.n + x];
 			if (!__builtin_isfinite(live))
 				live = sum / 16.0f;			/* display.cl:206-207 */
 			live = live * decay + sum * p.alpha;		/* display.cl:210-211 */
@@ -1125,13 +1305,13 @@ void k3_merge(const K3Params p)
 		}
 		const float vx = ((float)i / (float)half) - 1.0f;	/* display.cl:209,293 */
 		p.spectrum[i]      = make_float2(vx, live);
-		p.spectrum[kN + i] = make_float2(vx, mh);
+		p.spectrum[p.n + i] = make_float2(vx, mh);
 	}
 }
 
 hipError_t launch_k3(const K3Params &p, hipStream_t s)
 {
-	const int threads = p.n_bins * kN + kN;
+	const int threads = p.n_bins * p.n + p.n;
 	hipLaunchKernelGGL(k3_merge, dim3((threads + 255) / 256), dim3(256), 0, s, p);
 	return hipGetLastError();
 }

@@ -474,3 +474,57 @@ def test_sink_waterfall_matches_oracle(amd, torch_cuda, oracle_built):
     assert_close(wf, o.waterfall, "sink waterfall")
     L.fosphor_amd_sink_stop(s)
     L.fosphor_amd_sink_free(s)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config C3 geometry: N = 8192, 512 bins, 50 % overlap  (no reference behaviour exists
+# beyond N = 1024 / 128 bins: the oracle's generalisation defines it -- parity unpinned)
+# ---------------------------------------------------------------------------
+
+def test_fft8192_bit_exact(amd, torch_cuda, oracle_built):
+    torch = torch_cuda
+    f = amd.Fosphor(fft_len_log=13, n_bins=512, max_spectra=64)
+    o = Oracle(fft_len_log=13, n_bins=512)
+    x = gaussian_iq(8 * 8192, 80, sigma=1.0).reshape(8, 8192, 2)
+    x[3] *= 1e-4
+    x[5, 17, 0] = np.nan
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    assert f.fft_device(d_in, d_out, 8) == 0
+    want = Oracle.fft(x, o.window, fft_len_log=13)
+    got = d_out.cpu().numpy()
+    assert np.array_equal(canon_bits(got), canon_bits(want)), "%d words differ" % (canon_bits(got) != canon_bits(want)).sum()
+    # and it is a DFT
+    ref = np.fft.fft((x[0, :, 0].astype(np.float64) + 1j * x[0, :, 1]) * o.window.astype(np.float64))
+    g = got[0, :, 0].astype(np.float64) + 1j * got[0, :, 1]
+    assert np.max(np.abs(g - ref)) / np.max(np.abs(ref)) < 1e-6
+    f.close()
+
+
+def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built):
+    """8192-point FFT, 512 bins, overlap 2 fused into the read, two launches with state carry-over."""
+    torch = torch_cuda
+    n, nb, overlap = 8192, 512, 2
+    hop = n // overlap
+    f = amd.Fosphor(fft_len_log=13, n_bins=nb, max_spectra=128)
+    o = Oracle(fft_len_log=13, n_bins=nb)
+    assert f.histo_scale == o.histo_scale and f.histo_offset == o.histo_offset
+    t0 = 0
+    for call, n_spec in enumerate([32, 64]):
+        x = add_tone(gaussian_iq((n_spec - 1) * hop + n, 81 + call), 0.05, 0.0313, t0=t0)
+        t0 += x.shape[0]
+        expanded = np.concatenate([x[i * hop:i * hop + n] for i in range(n_spec)])
+        assert f.process_device_overlap(torch.from_numpy(x).cuda(), 1, n_spec, overlap) == 0
+        assert o.process(expanded, strict=False, nthreads=8) == 0
+        assert f.waterfall_pos == o.waterfall_pos
+        assert np.array_equal(f.hitcount, o.hitcount.T), "call %d: hit counts" % call
+        rows = (o.waterfall_pos - n_spec + np.arange(n_spec)) & 1023
+        assert_close(f.waterfall[rows], o.waterfall[rows], "C3 waterfall")
+        assert_close(f.spectrum[0, :, 1], o.spectrum[0, :, 1], "C3 live")
+        assert_close(f.spectrum[1, :, 1], o.spectrum[1, :, 1], "C3 max-hold")
+        assert_hist_close(f.histogram, o.histogram, "C3 histogram")
+    # host path: len must be a multiple of 16 * 8192 here
+    assert f.process(np.zeros((16 * 1024, 2), np.float32)) == -errno.EINVAL
+    assert f.process(gaussian_iq(16 * 8192, 83)) == 0 and o.process(gaussian_iq(16 * 8192, 83)) == 0
+    assert np.array_equal(f.hitcount, o.hitcount.T)
+    f.close()
