@@ -77,7 +77,7 @@ struct fosphor
 	hipEvent_t ev_set_free[kSets];		/* K2 finished reading set pp */
 	int       set_used[kSets];
 	int       overlap;			/* 1: two-stream pipeline for process paths */
-	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 = wave per spectrum, 2 = two waves per spectrum */
+	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
 	int       last_hc16;
@@ -307,7 +307,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
 		self->overlap = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_K1");
-		self->k1_variant = (e && *e == '1') ? 1 : 2;
+		self->k1_variant = (e && *e == '2') ? 2 : 1;
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
@@ -490,6 +490,8 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->kappa = kappa;
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
 	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : 3;
+	if (k1->variant == 1 && (k1->hop & 1))
+		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }

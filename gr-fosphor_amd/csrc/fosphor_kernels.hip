@@ -278,6 +278,9 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #ifndef K1_PREFETCH
 #define K1_PREFETCH 1			/* register prefetch of the next spectrum */
 #endif
+#ifndef K1_LOAD16
+#define K1_LOAD16 1			/* 1: 16-byte IQ loads, lane L owns pass-1 items 2L and 2L+1; 0: 8-byte loads, items L and L+64 */
+#endif
 #ifndef K1_TW3_LDS
 #define K1_TW3_LDS 0			/* pass-3 twiddles from an LDS table instead of registers */
 #endif
@@ -294,6 +297,23 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #define K1_STAMP(i) do { } while (0)
 #endif
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#if K1_LOAD16
+/* 8 x (64 lanes x 16 B) = 1 KiB per instruction, read-once: non-temporal.  `src` points at this
+ * lane's pair: elements (2L, 2L+1) + 128k land in x[2k], x[2k+1].  (Ablation on MI355X: with
+ * 8-byte-per-lane loads the load path alone caps K1 near 4.7 TB/s; 16-byte ones do not.) */
+static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__restrict__ src)
+{
+#pragma unroll
+	for (int k = 0; k < 8; k++) {
+		const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 128 * k));
+		x[2 * k]     = v2f{ q.x, q.y };
+		x[2 * k + 1] = v2f{ q.z, q.w };
+	}
+}
+#define K1_LANE_SRC(lane) (2 * (lane))
+#else
 /* 16 x (64 lanes x 8 B) coalesced, read-once: non-temporal */
 static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__restrict__ src)
 {
@@ -301,6 +321,8 @@ static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__r
 	for (int m = 0; m < 16; m++)
 		x[m] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + 64 * m));
 }
+#define K1_LANE_SRC(lane) (lane)
+#endif
 
 template <bool WRITE_FFT>
 __global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
@@ -356,7 +378,10 @@ void k1_fft_bin(const K1Params p)
 	 * pattern are derived in DESIGN.md ("LDS exchange").                    */
 	const int rd_even = lane ^ ((lane >> 3) & 7);		/* e = lane + 64m, m even */
 	const int rd_odd  = rd_even ^ 8;			/*                 m odd  */
-	const int st1     = (8 * lane) ^ (lane & 15);		/* pass 1: e = 8i + jj    */
+	const int st1     = (8 * lane) ^ (lane & 15);		/* pass 1: e = 8i + jj, i = lane (+64v)   */
+	const int st1a    = (16 * lane) ^ ((2 * lane) & 15);		/* pass 1, i = 2 lane     */
+	const int st1b    = (16 * lane + 8) ^ ((2 * lane + 1) & 15);	/* pass 1, i = 2 lane + 1 */
+	(void)st1; (void)st1a; (void)st1b;
 	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);	/* pass 2: e = 64(i>>3)+(i&7)+8jj */
 
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
@@ -364,7 +389,7 @@ void k1_fft_bin(const K1Params p)
 
 	v2f xn[16];
 #if K1_PREFETCH
-	load_iq16(xn, p.iq + (size_t)tile * p.tile * p.hop + lane);
+	load_iq16(xn, p.iq + (size_t)tile * p.tile * p.hop + K1_LANE_SRC(lane));
 #endif
 #if K1_TIMING
 	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -395,10 +420,18 @@ void k1_fft_bin(const K1Params p)
 			v2f x[16];
 
 #if !K1_PREFETCH
-			load_iq16(xn, p.iq + (size_t)t * p.hop + lane);
+			load_iq16(xn, p.iq + (size_t)t * p.hop + K1_LANE_SRC(lane));
 #endif
 			K1_STAMP(7);		/* loop overhead + stores of the previous iteration */
-			/* window (fft.cl:415-417); taps fetched as pairs (m, m+1) */
+			/* window (fft.cl:415-417); taps fetched as pairs */
+#if K1_LOAD16
+#pragma unroll
+			for (int k = 0; k < 8; k++) {	/* x[2k], x[2k+1] = elements 2L + 128k, 2L + 1 + 128k */
+				const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * k]);
+				x[2 * k]     = mul_bcast_lo(xn[2 * k], w);
+				x[2 * k + 1] = mul_bcast_hi(xn[2 * k + 1], w);
+			}
+#else
 #pragma unroll
 			for (int m = 0; m < 16; m += 2) {
 				v2f w;
@@ -407,6 +440,7 @@ void k1_fft_bin(const K1Params p)
 				x[m]     = mul_bcast_lo(xn[m], w);
 				x[m + 1] = mul_bcast_hi(xn[m + 1], w);
 			}
+#endif
 
 #if K1_PREFETCH
 			/* prefetch the next spectrum this wave will process */
@@ -414,13 +448,15 @@ void k1_fft_bin(const K1Params p)
 				const bool last = (g0 + u + 1 == p.tile);
 				const int t_next = last ? (tile + stride) * p.tile : t + 1;
 				if (!last || tile + stride < ntiles)
-					load_iq16(xn, p.iq + (size_t)t_next * p.hop + lane);
+					load_iq16(xn, p.iq + (size_t)t_next * p.hop + K1_LANE_SRC(lane));
 			}
 #endif
 
 			K1_STAMP(0);		/* window (includes waiting for the prefetched IQ) + prefetch issue */
 			/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) --------
-			 * virtual work-item i = lane + 64v owns elements i + 128j = lane + 64(v + 2j) */
+			 * K1_LOAD16: this lane is virtual work-items i = 2L + v (elements i + 128j = x[2j + v]);
+			 * otherwise i = lane + 64v (elements lane + 64(v + 2j) = x[v + 2j]).  Either way item i
+			 * stores its outputs at e = 8i + jj; which lane runs which item is free. */
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
 				v2f r[8];
@@ -430,7 +466,11 @@ void k1_fft_bin(const K1Params p)
 				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
+#if K1_LOAD16
+					buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
+#else
 					buf[(st1 ^ jj) + 512 * v] = r[R8_PERM(jj)];
+#endif
 			}
 			wave_lds_sync();
 #pragma unroll
@@ -459,28 +499,33 @@ void k1_fft_bin(const K1Params p)
 			wave_lds_sync();
 
 			K1_STAMP(2);		/* pass 2 + exchange */
-			/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426) ------------------ */
+			/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426) ------------------
+			 * Virtual item i = lane + 64v stores its outputs at e = 512v + lane + 64jj, and the
+			 * pass-4 butterflies of this lane read exactly e = lane + 64m: with both items of a
+			 * pair in the same lane the third exchange is the identity x[jj + 8v] = out_v[jj] --
+			 * no LDS round trip (fft.cl:347-349 + 435-438 collapse to register renaming). */
+			{
+				v2f y[16];
 #pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-				r[0] = x[v];
+				for (int v = 0; v < 2; v++) {
+					v2f r[8];
+					r[0] = x[v];
 #pragma unroll
-				for (int j = 1; j < 8; j++)
+					for (int j = 1; j < 8; j++)
 #if K1_TW3_LDS
-					r[j] = c_mul(x[v + 2 * j], tw3_tab[j - 1][lane]);
+						r[j] = c_mul(x[v + 2 * j], tw3_tab[j - 1][lane]);
 #else
-					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
+						r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
 #endif
-				dft8(r, s12);
+					dft8(r, s12);
 #pragma unroll
-				for (int jj = 0; jj < 8; jj++)	/* e = 512v + lane + 64jj */
-					buf[((jj & 1) ? rd_odd : rd_even) + 64 * jj + 512 * v] = r[R8_PERM(jj)];
+					for (int jj = 0; jj < 8; jj++)
+						y[jj + 8 * v] = r[R8_PERM(jj)];
+				}
+#pragma unroll
+				for (int m = 0; m < 16; m++)
+					x[m] = y[m];
 			}
-			wave_lds_sync();
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
-			wave_lds_sync();
 
 			K1_STAMP(3);		/* pass 3 + exchange */
 			/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) ------------------
