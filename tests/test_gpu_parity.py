@@ -528,3 +528,51 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built):
     assert f.process(gaussian_iq(16 * 8192, 83)) == 0 and o.process(gaussian_iq(16 * 8192, 83)) == 0
     assert np.array_equal(f.hitcount, o.hitcount.T)
     f.close()
+
+
+@pytest.mark.parametrize("n_bins,wf_rows,consts", [
+    (16, 1024, None), (64, 256, None), (192, 1024, (4.0, 256.0, 0.01)), (256, 2048, (32.0, 4096.0, 0.0005)),
+])
+def test_geometry_and_constant_variants(amd, torch_cuda, oracle_built, n_bins, wf_rows, consts):
+    """Bins 16..256, waterfall depth, rise/decay/averaging constants (cl.c:714-716) other than the
+    reference's: oracle-defined generalisations, same parity bars."""
+    kw = {}
+    if consts:
+        kw = dict(t0r=consts[0], t0d=consts[1], alpha=consts[2])
+    f = amd.Fosphor(n_bins=n_bins, wf_rows=wf_rows, max_spectra=2048, **kw)
+    o = Oracle(n_bins=n_bins, wf_rows=wf_rows)
+    if consts:
+        o.set_constants(*consts)
+    f.set_power_range(-10, 5)
+    o.set_power_range(-10, 5)
+    import torch
+    for k, b in enumerate([48, 1024, 2048, 16]):
+        x = add_tone(gaussian_iq(b * 1024, 200 + k), 0.02, 0.4, t0=k * 7)
+        if b <= 1024:
+            assert f.process(x) == 0
+        else:			# beyond the host-side cap (cl.c:885): device path, one display launch
+            assert f.process(x) == -errno.EINVAL
+            assert f.process_device(torch.from_numpy(x).cuda(), 1, b) == 0
+        assert o.process(x, strict=False, nthreads=8) == 0
+        compare_state(f, o, "bins %d rows %d call %d" % (n_bins, wf_rows, k))
+    f.close()
+
+
+def test_capacity_and_argument_errors(amd, torch_cuda):
+    torch = torch_cuda
+    f = amd.Fosphor(max_spectra=64, max_batches=2)
+    d = torch.zeros((64 * 1024, 2), dtype=torch.float32, device="cuda")
+    assert f.process_device(d, 1, 64) == 0
+    assert f.process_device(d, 1, 80) == -errno.EINVAL		# over capacity
+    assert f.process_device(d, 4, 16) == -errno.EINVAL		# more batches than max_batches
+    assert f.process_device(d, 1, 24) == -errno.EINVAL		# not a multiple of 16 spectra
+    assert f.process_device(d, 0, 16) == -errno.EINVAL
+    assert f.accumulate_device(d, 32, 8, 64) == -errno.EINVAL	# shard offset not on a 16-spectrum boundary
+    assert f.accumulate_device(d, 32, 48, 64) == -errno.EINVAL	# shard runs past the batch
+    with pytest.raises(RuntimeError):
+        amd.Fosphor(n_bins=100)					# not a multiple of 16
+    with pytest.raises(RuntimeError):
+        amd.Fosphor(wf_rows=1000)				# not a power of two
+    with pytest.raises(RuntimeError):
+        amd.Fosphor(fft_len_log=11)				# only 2^10 and 2^13 in this round
+    f.close()
