@@ -21,6 +21,9 @@ waterfall, 1xMI355X); per-GPU work is the same at every N (weak scaling, configs
          frame k overlaps the FFT of frame k+1.
 
 The input ring is larger than the 256 MiB Infinity Cache so IQ reads come from HBM.
+The defaults (32768 steps = 34 G samples, ~80 ms) are long enough to be past the first few
+milliseconds of a run, during which the clocks are still settling and K1 -- which is VALU- and
+power-bound -- runs 10-30 % slower (measured: 1280 steps 390 GS/s, 25600 steps 436, 102400 steps 454).
 
 roofline: the dominant kernel is K1 (fft_bin).  achieved = 8 B x samples per launch / mean K1
 duration, measured with hipEvents on the library's stream inside the timed region.
@@ -47,8 +50,8 @@ BYTES_PER_SAMPLE = 8		# algorithmic read, one complex fp32 sample
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1280)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=32768)
+    ap.add_argument("--warmup", type=int, default=2048)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--batches-per-launch", type=int, default=64)
     ap.add_argument("--ring-batches", type=int, default=128, help="distinct batches of IQ resident in HBM (8 MiB each)")
@@ -147,21 +150,32 @@ def main():
 
     pos = run_steps(args.warmup, 0)
     sync()
-    f.profile(True)
+    # timed region: hipEvents around K1 only (events around K2/K3 too cost ~6 % of throughput:
+    # they sit on the critical path of the count/merge streams)
+    if not os.environ.get("BENCH_NO_PROFILE"):	# debugging aid: cost of the hipEvents themselves
+        f.profile(2)
     t0 = time.perf_counter()
     run_steps(args.steps, pos)
     sync()
     elapsed = time.perf_counter() - t0
     ms, launches = f.kernel_times()
 
+    # K2 / K3 durations in the pipeline (informational): a short extra pass with events around
+    # every kernel, outside the timed region
+    f.profile(1)
+    run_steps(8 * F, 0)
+    f.kernel_times()
+    run_steps(32 * F, 0)
+    ms_all, n_all = f.kernel_times()
+
     # K1 alone (same launches, K2/K3 not running beside it): a short extra pass outside the
     # timed region, reported as roofline.isolated
     iso = None
     if mode == "batch":
         f.set_overlap(False)
-        run_steps(2 * F, 0)
+        run_steps(8 * F, 0)
         f.kernel_times()
-        run_steps(4 * F, 0)
+        run_steps(32 * F, 0)
         ms_i, n_i = f.kernel_times()
         f.set_overlap(True)
         if n_i[0]:
@@ -179,7 +193,7 @@ def main():
     if rank == 0:
         k1_ms = ms[0] / max(1, launches[0])
         samples_per_launch = args.steps * samples_per_batch / max(1, launches[0])
-        achieved = BYTES_PER_SAMPLE * samples_per_launch / (k1_ms * 1e-3) / 1e9
+        achieved = BYTES_PER_SAMPLE * samples_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
         isolated = None
@@ -194,6 +208,8 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        k1_name = "k1v2_fft_bin (K1, two waves per spectrum)" if os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2" \
+            else "k1_fft_bin (K1, one wave per spectrum)"
         out = {
             "metric": "complex IQ MSamples/s @1024-pt FFT",
             "value": value, "unit": "MSamples/s",
@@ -207,11 +223,11 @@ def main():
                 "input": "white complex Gaussian sigma=0.05, fp32 IQ resident in HBM (%d MiB ring)" % (ring * 8),
                 "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d steps" % F,
             },
-            "roofline": {"bound": "hbm", "kernel": "k1v2_fft_bin (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
-                         "k2_ms_per_launch": ms[1] / max(1, launches[1]),
-                         "k3_ms_per_launch": ms[2] / max(1, launches[2]),
+                         "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
+                         "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch,
                          "isolated": isolated},
         }

@@ -152,7 +152,8 @@ class Fosphor:
 
     # ---- measurement --------------------------------------------------------
     def profile(self, enable=True):
-        self.L.fosphor_amd_profile(self.h, 1 if enable else 0)
+        """False/0: off; True/1: hipEvents around every kernel; 2: around K1 only."""
+        self.L.fosphor_amd_profile(self.h, 2 if enable == 2 and enable is not True else (1 if enable else 0))
 
     def set_overlap(self, enable):
         return self.L.fosphor_amd_set_overlap(self.h, 1 if enable else 0)

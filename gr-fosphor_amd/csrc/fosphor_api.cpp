@@ -72,7 +72,15 @@ struct fosphor
 	uint32_t *d_bins;			/* current set */
 	float2   *d_partial;
 	int       pp;
-	hipStream_t stream2;			/* K2/K3 of the multi-batch path */
+	hipStream_t stream2;			/* K2 (and K3 unless pipe3) of the multi-batch path */
+	hipStream_t stream3;			/* K3 of the multi-batch path: K3 of launch i beside K2 of launch i+1 */
+	int       pipe3;			/* FOSPHOR_AMD_PIPE3=0 keeps K3 on stream2 */
+	int       hset;				/* hit-count / live-sum set of the next launch (two, like the bin sets) */
+	int       hset_used[2];
+	hipEvent_t ev_k2_done[2];		/* K2 wrote hit-count set h */
+	hipEvent_t ev_h_free[2];		/* K3 finished reading hit-count set h */
+	hipEvent_t ev_k3_done;			/* orders K3s that are issued on different streams */
+	hipStream_t last_k3_stream;
 	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
 	hipEvent_t ev_set_free[kSets];		/* K2 finished reading set pp */
 	int       set_used[kSets];
@@ -111,7 +119,8 @@ struct fosphor
 	bool rise_ok(int batch) const { return batch <= 8192; }
 
 	/* profiling */
-	int prof;
+	int prof;				/* 0 off, 1 every kernel, 2 K1 only (fewer events beside K2/K3) */
+	int prof_open;
 	std::vector<hipEvent_t> ev_pool;
 	std::vector<int> ev_kind;		/* kernel index per (start, stop) pair */
 	size_t ev_used;
@@ -184,6 +193,17 @@ static void build_thresholds(double *thr, int nb, float hs, float ho)
 /* Init / release                                                           */
 /* ------------------------------------------------------------------------ */
 
+/* Events that order kernels of this device among the instance's own streams (and the timing
+ * events) need no system-scope fence: a default event makes the queue write back and invalidate
+ * the L2s when it is recorded, which costs microseconds between dependent kernels and sends the
+ * consumer's reads to HBM.  Kernel boundaries keep their device-scope release/acquire.
+ * (Events the HOST waits on for host-visible data -- staging, upload -- keep the default.) */
+static unsigned dep_event_flags(void)
+{
+	const char *e = getenv("FOSPHOR_AMD_SYSFENCE");
+	return (e && *e == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+
 extern "C" const char *fosphor_amd_version(void) { return FOSPHOR_AMD_VERSION; }
 
 extern "C" void fosphor_release(struct fosphor *self)
@@ -200,6 +220,12 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_set_free[i]) (void)hipEventDestroy(self->ev_set_free[i]);
 	}
 	if (self->stream2) { (void)hipStreamSynchronize(self->stream2); (void)hipStreamDestroy(self->stream2); }
+	if (self->stream3) { (void)hipStreamSynchronize(self->stream3); (void)hipStreamDestroy(self->stream3); }
+	for (int i = 0; i < 2; i++) {
+		if (self->ev_k2_done[i]) (void)hipEventDestroy(self->ev_k2_done[i]);
+		if (self->ev_h_free[i]) (void)hipEventDestroy(self->ev_h_free[i]);
+	}
+	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
@@ -293,12 +319,18 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	for (int i = 0; i < kSets; i++) {
 		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * self->n * (self->bins16 ? 2 : 1)), "alloc bin indices");
 		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * self->n), "alloc partials");
-		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], hipEventDisableTiming), "create event");
-		HIP_TRY(hipEventCreateWithFlags(&self->ev_set_free[i], hipEventDisableTiming), "create event");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], dep_event_flags()), "create event");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_set_free[i], dep_event_flags()), "create event");
 	}
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	for (int i = 0; i < 2; i++) {
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_k2_done[i], dep_event_flags()), "create event");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
+	}
+	HIP_TRY(hipEventCreateWithFlags(&self->ev_k3_done, dep_event_flags()), "create event");
 	if (getenv("FOSPHOR_AMD_K1_TIMING")) {
 		HIP_TRY(hipMalloc((void **)&self->d_dbg, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "alloc timing buffer");
 		HIP_TRY(hipMemset(self->d_dbg, 0, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "clear timing buffer");
@@ -308,11 +340,14 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->overlap = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_K1");
 		self->k1_variant = (e && *e == '2') ? 2 : 1;
+		e = getenv("FOSPHOR_AMD_PIPE3");
+		self->pipe3 = (e && *e == '1');
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
-	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * (size_t)self->max_batches * self->n), "alloc live sums");
-	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * (size_t)self->max_batches * self->n), "alloc max");
+	/* two sets of max_batches slots (the 16-bit hit counts of the second set use the upper half of d_hc) */
+	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * 2 * (size_t)self->max_batches * self->n), "alloc live sums");
+	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * 2 * (size_t)self->max_batches * self->n), "alloc max");
 	HIP_TRY(hipMalloc((void **)&self->d_chunk_sum, sizeof(float) * (size_t)(self->max_spectra / 16) * self->n), "alloc chunk sums");
 	HIP_TRY(hipMalloc((void **)&self->d_chunk_max, sizeof(float) * (size_t)(self->max_spectra / 16) * self->n), "alloc chunk max");
 	HIP_TRY(hipMalloc((void **)&self->d_rise, sizeof(float2) * (kRiseMax + 1)), "alloc rise table");
@@ -394,24 +429,64 @@ extern "C" void fosphor_set_frequency_range(struct fosphor *self, double center,
 
 static void prof_begin(struct fosphor *self, int kind, hipStream_t st)
 {
-	if (!self->prof) return;
+	self->prof_open = 0;
+	if (!self->prof || (self->prof == 2 && kind != 0)) return;
 	if (self->ev_used + 2 > self->ev_pool.size()) {
 		for (int i = 0; i < 2; i++) {
 			hipEvent_t e;
-			if (hipEventCreate(&e) != hipSuccess) return;
+			if (hipEventCreateWithFlags(&e, dep_event_flags() & ~hipEventDisableTiming) != hipSuccess) return;
 			self->ev_pool.push_back(e);
 		}
 	}
+	self->prof_open = 1;
 	self->ev_kind.push_back(kind);
 	(void)hipEventRecord(self->ev_pool[self->ev_used], st);
 }
 
 static void prof_end(struct fosphor *self, hipStream_t st)
 {
-	if (!self->prof) return;
+	if (!self->prof_open) return;
+	self->prof_open = 0;
 	if (self->ev_used + 2 > self->ev_pool.size()) return;
 	(void)hipEventRecord(self->ev_pool[self->ev_used + 1], st);
 	self->ev_used += 2;
+}
+
+static int sync_all(struct fosphor *self)
+{
+	int rv = 0;
+	if (self->stream  && hipStreamSynchronize(self->stream)  != hipSuccess) rv = -EIO;
+	if (self->stream2 && hipStreamSynchronize(self->stream2) != hipSuccess) rv = -EIO;
+	if (self->stream3 && hipStreamSynchronize(self->stream3) != hipSuccess) rv = -EIO;
+	return rv;
+}
+
+/* K3s update the persistent state in launch order.  They normally follow each other on one
+ * stream; when the stream changes (pipelined process path <-> accumulate/merge path) the new
+ * stream waits for the last K3 of the old one. */
+static int k3_stream_enter(struct fosphor *self, hipStream_t st)
+{
+	if (self->last_k3_stream && self->last_k3_stream != st) {
+		if (hipEventRecord(self->ev_k3_done, self->last_k3_stream) != hipSuccess ||
+		    hipStreamWaitEvent(st, self->ev_k3_done, 0) != hipSuccess)
+			return -EIO;
+	}
+	self->last_k3_stream = st;
+	return 0;
+}
+
+/* Before anything else than the pipelined 16-bit path writes d_hc / live sums: K3s still
+ * reading the two hit-count sets must be done. */
+static int drain_h_sets(struct fosphor *self, hipStream_t st)
+{
+	for (int h = 0; h < 2; h++) {
+		if (self->hset_used[h]) {
+			if (hipStreamWaitEvent(st, self->ev_h_free[h], 0) != hipSuccess)
+				return -EIO;
+			self->hset_used[h] = 0;
+		}
+	}
+	return 0;
 }
 
 /* Upload lazily-changed tables (cl.c:889-900) and boot fills (cl.c:406-465, 930-934) */
@@ -499,7 +574,7 @@ static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } re
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
  * d_bins / d_partial; results land in slot `slot0`.. of hc / live_sum / vmax. */
 static int run_count(struct fosphor *self, int n_batches, int batch, int tile, int slot0,
-                     int t_offset, int weight_batch, hipStream_t st, int use16 = 0)
+                     int t_offset, int weight_batch, hipStream_t st, int use16 = 0, int hset = 0)
 {
 	K2Params k2; K2bParams k2b;
 	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
@@ -509,15 +584,17 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
-	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch)) ? (uint16_t *)self->d_hc : NULL;
+	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch))
+	          ? (uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
+	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
 	if (cpb == 1) {
-		k2.chunk_sum = self->d_live_sum + (size_t)slot0 * self->n;
-		k2.chunk_max = self->d_vmax + (size_t)slot0 * self->n;
+		k2.chunk_sum = self->d_live_sum + (size_t)lslot * self->n;
+		k2.chunk_max = self->d_vmax + (size_t)lslot * self->n;
 	} else {
 		k2.chunk_sum = self->d_chunk_sum;
 		k2.chunk_max = self->d_chunk_max;
@@ -527,8 +604,8 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	HIP_TRY(launch_k2(k2, n_batches * cpb, st), "launch count");
 	if (cpb > 1) {
 		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
-		k2b.live_sum = self->d_live_sum + (size_t)slot0 * self->n;
-		k2b.vmax = self->d_vmax + (size_t)slot0 * self->n;
+		k2b.live_sum = self->d_live_sum + (size_t)lslot * self->n;
+		k2b.vmax = self->d_vmax + (size_t)lslot * self->n;
 		k2b.n_batches = n_batches; k2b.cpb = cpb; k2b.n = self->n;
 		HIP_TRY(launch_k2b(k2b, st), "launch chunk reduce");
 	}
@@ -546,8 +623,7 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 		return 0;
 	if (self->rise_batch == batch && self->rise_t0r == self->t0r && self->rise_t0d == self->t0d)
 		return 1;
-	(void)hipStreamSynchronize(self->stream);	/* h_rise may be in flight */
-	(void)hipStreamSynchronize(self->stream2);
+	(void)sync_all(self);				/* h_rise may be in flight */
 	for (int hc = 0; hc <= batch; hc++) {
 		const float a = (float)hc / (float)batch;
 		const float b = a * (1.0f / self->t0r);
@@ -562,21 +638,23 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 	return 1;
 }
 
-static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0)
+static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0, int hset = 0)
 {
 	K3Params k3;
 	const size_t cells = (size_t)self->n_bins * self->n;
+	const int lslot = slot0 + hset * self->max_batches;
 	const int have_table = ensure_rise_table(self, batch, st);
-	if (have_table < 0)
+	if (have_table < 0 || k3_stream_enter(self, st))
 		return -EIO;
 	memset(&k3, 0, sizeof(k3));
 	k3.rise = have_table ? self->d_rise : NULL;
 	k3.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
 	k3.hc = self->d_hc + (size_t)slot0 * cells;
-	k3.hc16 = (use16 && batch <= 1024 && have_table) ? (const uint16_t *)self->d_hc : NULL;
+	k3.hc16 = (use16 && batch <= 1024 && have_table)
+	          ? (const uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	k3.hc_export = self->d_hc_export;
-	k3.live_sum = self->d_live_sum + (size_t)slot0 * self->n;
-	k3.vmax = self->d_vmax + (size_t)slot0 * self->n;
+	k3.live_sum = self->d_live_sum + (size_t)lslot * self->n;
+	k3.vmax = self->d_vmax + (size_t)lslot * self->n;
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
 	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins; k3.n = self->n;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
@@ -593,8 +671,11 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	const int total = n_batches * batch;
 	const int tile = pick_tile(total);
 	hipStream_t st2 = self->overlap ? self->stream2 : self->stream;
+	/* third stream: only the 16-bit count path has a second hit-count set */
+	const int three = self->overlap && self->pipe3 && batch <= 1024 && self->rise_ok(batch);
+	hipStream_t st3 = three ? self->stream3 : st2;
 	K1Params k1;
-	int set;
+	int set, hset = 0;
 
 	if (prepare(self))
 		return -EIO;
@@ -602,8 +683,10 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	/* Pipeline: K1 (VALU-bound) of this launch runs on `stream` while K2/K3 (memory- and
 	 * latency-bound) of the previous launch still run on `stream2`; the bin-index / partial
 	 * intermediates ping-pong between two sets.  K1 may reuse a set once the K2 that read
-	 * it has finished; K2 starts when its K1 has finished; K3s stay in launch order on
-	 * stream2, so the persistent state sees the batches in order. */
+	 * it has finished; K2 starts when its K1 has finished.  K3 (one work-group per CU beside K1,
+	 * like K2) gets a third stream and the hit counts a second set, so K3 of launch i runs
+	 * beside K2 of launch i+1; K3s stay in launch order on that stream, so the persistent state
+	 * sees the batches in order. */
 	set = self->pp;
 	self->pp = (self->pp + 1) % kSets;
 	self->d_bins = self->d_bins_pp[set];
@@ -621,14 +704,30 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
 		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
 	}
-	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2, 1))
+	if (three) {
+		hset = self->hset;
+		self->hset ^= 1;
+		if (self->hset_used[hset])
+			HIP_TRY(hipStreamWaitEvent(st2, self->ev_h_free[hset], 0), "wait for hit-count set");
+	} else if (drain_h_sets(self, st2)) {
+		return -EIO;
+	}
+	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2, 1, hset))
 		return -EIO;
 	if (self->overlap) {
 		HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
 		self->set_used[set] = 1;
 	}
-	if (run_merge(self, n_batches, batch, 0, st2, 1))
+	if (three) {
+		HIP_TRY(hipEventRecord(self->ev_k2_done[hset], st2), "record K2 done");
+		HIP_TRY(hipStreamWaitEvent(st3, self->ev_k2_done[hset], 0), "K3 waits for K2");
+	}
+	if (run_merge(self, n_batches, batch, 0, st3, 1, hset))
 		return -EIO;
+	if (three) {
+		HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
+		self->hset_used[hset] = 1;
+	}
 	self->last_hc16 = (batch <= 1024 && batch <= kRiseMax);
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
@@ -742,7 +841,7 @@ extern "C" int fosphor_amd_finish(struct fosphor *self)
 		if (prepare(self))
 			return -EIO;
 	}
-	if (hipStreamSynchronize(self->stream) != hipSuccess || hipStreamSynchronize(self->stream2) != hipSuccess)
+	if (sync_all(self))
 		return -EIO;
 	self->state = ST_READY;
 	return 1;
@@ -810,7 +909,7 @@ extern "C" int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_o
 	int saved_state;
 	if (!self || !d_in || !d_out || n_spectra < 4 || (n_spectra & 3) || n_spectra > self->max_spectra)
 		return -EINVAL;
-	(void)hipStreamSynchronize(self->stream2);	/* scratch sets may still be read by a queued K2 */
+	(void)sync_all(self);				/* scratch sets may still be read by a queued K2 */
 	saved_state = self->state;
 	self->state = ST_READY;			/* no boot fills for a pure FFT */
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -831,7 +930,7 @@ extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_
 	if (!self || !d_fft || !d_bin || !d_pwr || n < 1)
 		return -EINVAL;
 	if (e && *e == '1') force = 1;
-	(void)hipStreamSynchronize(self->stream2);
+	(void)sync_all(self);
 	saved_state = self->state;
 	self->state = ST_READY;
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -882,6 +981,8 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
 		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
 	}
+	if (drain_h_sets(self, st2))
+		return -EIO;
 	if (run_count(self, 1, n_local, tile, self->slot, t_offset, total_batch, st2))
 		return -EIO;
 	if (self->overlap) {
@@ -940,14 +1041,14 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 
 extern "C" void fosphor_amd_profile(struct fosphor *self, int enable)
 {
-	self->prof = enable ? 1 : 0;
+	self->prof = enable == 2 ? 2 : (enable ? 1 : 0);
 }
 
 extern "C" int fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3])
 {
 	if (!self)
 		return -EINVAL;
-	if (hipStreamSynchronize(self->stream) != hipSuccess || hipStreamSynchronize(self->stream2) != hipSuccess)
+	if (sync_all(self))
 		return -EIO;
 	for (int i = 0; i < 3; i++) { ms[i] = 0.0f; launches[i] = 0; }
 	for (size_t i = 0; i + 1 < self->ev_used; i += 2) {
@@ -1021,6 +1122,7 @@ extern "C" int fosphor_amd_set_overlap(struct fosphor *self, int enable)
 		return -EIO;
 	self->overlap = enable ? 1 : 0;
 	self->set_used[0] = self->set_used[1] = 0;
+	self->hset_used[0] = self->hset_used[1] = 0;
 	return 0;
 }
 

@@ -54,7 +54,7 @@ struct K1Params {
 };
 
 /* K2: bin indices -> hit counts + live sum / max per column.
- * Grid (N/16 column slabs, chunks): a chunk is `chunk` consecutive spectra of one batch.
+ * Grid (N/64 column slabs, chunks): a chunk is `chunk` consecutive spectra of one batch.
  * chunks_per_batch == 1: counts are stored; otherwise they are added with integer atomics
  * into hc[f] (zeroed by the host first) -- integer sums are order-independent, so the result
  * is bit-identical either way.  Float partials go out per chunk and are reduced in a fixed
@@ -63,7 +63,8 @@ struct K2Params {
 	const uint32_t *bins;		/* [total/4][N] */
 	const float2   *partial;	/* [total/tile][N] */
 	uint32_t *hc;			/* [n_batches][n_bins][N] */
-	uint16_t *hc16;			/* or (batch <= 1024, one chunk per batch): [n_batches][N/16][n_bins][16] */
+	uint16_t *hc16;			/* or (batch <= 1024, one chunk per batch): [n_batches][N/64][n_bins][32] dwords,
+					 * columns c and c + 32 of the slab in the low / high half */
 	float    *chunk_sum;		/* [n_chunks][N] */
 	float    *chunk_max;		/* [n_chunks][N] */
 	int   n;			/* FFT length (columns) */

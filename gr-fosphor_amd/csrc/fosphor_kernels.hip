@@ -1082,84 +1082,118 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
 }
 
 /* ------------------------------------------------------------------------ */
-/* K2: hit counts per (slab of 16 columns, batch)                            */
+/* K2: hit counts per (slab of 64 columns, chunk)                            */
 /* ------------------------------------------------------------------------ */
 
+/* One lane per column: the 64 lanes of a wave count 64 different columns, so an LDS atomic
+ * never meets a bank conflict between different (bin, column) cells.  Columns c and c + 32 of
+ * the slab share one dword (low / high 16 bits; a chunk has <= 1024 spectra, so the low half
+ * cannot carry into the high one): the two lanes that meet in a bank are serialised by the
+ * hardware either way, and the histogram is half the size (32 KiB at 256 bins), which lets a
+ * work-group of this kernel sit beside the two K1 work-groups of a CU.
+ * (The previous layout, display.cl:96,176's [bin][16] with 4 spectra x 16 columns per wave,
+ * had 4 lanes per column in every atomic instruction and kept the LDS pipe busy ~3x longer.) */
+#ifndef K2_INFLIGHT
+#define K2_INFLIGHT 4
+#endif
 __global__ __launch_bounds__(256)
 void k2_count(const K2Params p)
 {
-	extern __shared__ uint32_t h[];			/* [n_bins][16]: bin-major as display.cl:96,176 */
-	__shared__ float red_s[16][17], red_m[16][17];
+	extern __shared__ uint32_t h[];			/* [n_bins][32] packed pairs */
+	__shared__ float red_s[4][64], red_m[4][64];
 
 	const int tid  = threadIdx.x;
-	const int col  = tid & 15;
-	const int row  = tid >> 4;
-	const int x0   = blockIdx.x * 16;
+	const int lane = tid & 63;
+	const int wv   = tid >> 6;
+	const int x0   = blockIdx.x * 64;
 	const int c    = blockIdx.y;			/* chunk index within the launch */
 	const int cpb  = p.batch / p.chunk;		/* chunks per batch */
 	const int f    = c / cpb;			/* batch index */
 	const int t_in = (c - f * cpb) * p.chunk;	/* first spectrum of the chunk within its batch */
 	const int nb   = p.n_bins;
+	const int hcol = lane & 31;
+	const uint32_t inc = (lane & 32) ? 0x10000u : 1u;
 
-	for (int i = tid; i < nb * 16; i += 256)
+	for (int i = tid; i < nb * 32; i += 256)
 		h[i] = 0;
 	__syncthreads();
 
 	/* bins: one dword = 4 consecutive spectra of one column (8-bit indices), or 2 (16-bit
-	 * indices, n_bins > 256) */
+	 * indices, n_bins > 256 or N > 1024); a wave reads 256 contiguous bytes per row */
+	/* (uniform base pointer + 32-bit lane offsets: one address register per load in flight) */
 	if (p.bins16) {
-		const uint32_t *src16 = p.bins + (size_t)c * (p.chunk >> 1) * p.n + x0 + col;
-		for (int q = row; q < (p.chunk >> 1); q += 16) {
-			const uint32_t v = src16[(size_t)q * p.n];
-			atomicAdd(&h[(v & 0xffffu) * 16 + col], 1u);
-			atomicAdd(&h[(v >> 16) * 16 + col], 1u);
-		}
-	}
-	const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * p.n + x0 + col;
-	const int nq = p.bins16 ? 0 : (p.chunk >> 2);
-	int q = row;
-	for (; q + 48 < nq; q += 64) {			/* 4 independent loads in flight per thread */
-		uint32_t v[4];
+		const uint32_t *src16 = p.bins + (size_t)c * (p.chunk >> 1) * p.n + x0;
+		const uint32_t nq16 = p.chunk >> 1, n = p.n;
+		uint32_t q = wv;
+#pragma unroll 1
+		for (; q + 4 * (K2_INFLIGHT - 1) < nq16; q += 4 * K2_INFLIGHT) {
+			uint32_t v[K2_INFLIGHT];
 #pragma unroll
-		for (int u = 0; u < 4; u++)
-			v[u] = src[(size_t)(q + 16 * u) * p.n];
+			for (int u = 0; u < K2_INFLIGHT; u++)
+				v[u] = src16[(q + 4 * u) * n + lane];
 #pragma unroll
-		for (int u = 0; u < 4; u++) {
-			atomicAdd(&h[((v[u]      ) & 0xff) * 16 + col], 1u);
-			atomicAdd(&h[((v[u] >>  8) & 0xff) * 16 + col], 1u);
-			atomicAdd(&h[((v[u] >> 16) & 0xff) * 16 + col], 1u);
-			atomicAdd(&h[((v[u] >> 24)       ) * 16 + col], 1u);
+			for (int u = 0; u < K2_INFLIGHT; u++) {
+				atomicAdd(&h[(v[u] & 0xffffu) * 32 + hcol], inc);
+				atomicAdd(&h[(v[u] >> 16) * 32 + hcol], inc);
+			}
 		}
-	}
-	for (; q < nq; q += 16) {
-		const uint32_t v = src[(size_t)q * p.n];
-		atomicAdd(&h[((v      ) & 0xff) * 16 + col], 1u);
-		atomicAdd(&h[((v >>  8) & 0xff) * 16 + col], 1u);
-		atomicAdd(&h[((v >> 16) & 0xff) * 16 + col], 1u);
-		atomicAdd(&h[((v >> 24)       ) * 16 + col], 1u);
+#pragma unroll 1
+		for (; q < nq16; q += 4) {
+			const uint32_t v = src16[q * n + lane];
+			atomicAdd(&h[(v & 0xffffu) * 32 + hcol], inc);
+			atomicAdd(&h[(v >> 16) * 32 + hcol], inc);
+		}
+	} else {
+		const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * p.n + x0;
+		const uint32_t nq = p.chunk >> 2, n = p.n;
+		uint32_t q = wv;
+#pragma unroll 1
+		for (; q + 4 * (K2_INFLIGHT - 1) < nq; q += 4 * K2_INFLIGHT) {	/* independent loads in flight per thread */
+			uint32_t v[K2_INFLIGHT];
+#pragma unroll
+			for (int u = 0; u < K2_INFLIGHT; u++)
+				v[u] = src[(q + 4 * u) * n + lane];
+#pragma unroll
+			for (int u = 0; u < K2_INFLIGHT; u++) {
+				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
+				atomicAdd(&h[((v[u] >>  8) & 0xff) * 32 + hcol], inc);
+				atomicAdd(&h[((v[u] >> 16) & 0xff) * 32 + hcol], inc);
+				atomicAdd(&h[((v[u] >> 24)       ) * 32 + hcol], inc);
+			}
+		}
+#pragma unroll 1
+		for (; q < nq; q += 4) {
+			const uint32_t v = src[q * n + lane];
+			atomicAdd(&h[((v      ) & 0xff) * 32 + hcol], inc);
+			atomicAdd(&h[((v >>  8) & 0xff) * 32 + hcol], inc);
+			atomicAdd(&h[((v >> 16) & 0xff) * 32 + hcol], inc);
+			atomicAdd(&h[((v >> 24)       ) * 32 + hcol], inc);
+		}
 	}
 
 	/* live sum: sum_t pwr_t (1-a)^(B-1-t) from the tile partials, which hold
 	 * sum_{t in tile} pwr_t (1-a)^(t_last - t) (display.cl:149-150) */
 	{
 		const int tiles = p.chunk / p.tile;
-		const float2 *pp = p.partial + (size_t)c * tiles * p.n + x0 + col;
+		const float2 *pp = p.partial + (size_t)c * tiles * p.n + x0 + lane;
 		float s = 0.0f, m = -1000.0f;
-		for (int j = row; j < tiles; j += 16) {
+#pragma unroll 2
+		for (int j = wv; j < tiles; j += 4) {
 			const float2 v = pp[(size_t)j * p.n];
 			const int t_last = p.t_offset + t_in + (j + 1) * p.tile - 1;
 			/* (1-a)^k as exp2(k log2(1-a)): relative error ~1e-6 where the weight is not negligible */
 			s += v.x * __builtin_amdgcn_exp2f(p.log2_w * (float)(p.weight_batch - 1 - t_last));
 			m = (m < v.y) ? v.y : m;
 		}
-		red_s[row][col] = s;
-		red_m[row][col] = m;
+		red_s[wv][lane] = s;
+		red_m[wv][lane] = m;
 	}
 	__syncthreads();
 
-	if (tid < 16) {
+	if (tid < 64) {
 		float s = 0.0f, m = -1000.0f;
-		for (int j = 0; j < 16; j++) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) {				/* fixed order: deterministic floats */
 			s += red_s[j][tid];
 			m = (m < red_m[j][tid]) ? red_m[j][tid] : m;
 		}
@@ -1168,19 +1202,25 @@ void k2_count(const K2Params p)
 	}
 
 	if (p.hc16) {
-		/* slab-major 16-bit counts: this work-group's [bin][16] block is contiguous (8 KiB at 256 bins) */
-		uint16_t *d16 = p.hc16 + ((size_t)f * ((p.n / 16)) + blockIdx.x) * nb * 16;
-		for (int i = tid; i < nb * 16; i += 256)
-			d16[i] = (uint16_t)h[i];
+		/* the LDS image as it is: [bin][32] packed pairs, one contiguous block per work-group
+		 * (32 KiB at 256 bins); K3 unpacks */
+		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)f * (p.n / 64) + blockIdx.x) * nb * 32;
+#pragma unroll 2
+		for (int i = tid; i < nb * 32; i += 256)
+			d[i] = h[i];
 		return;
 	}
-	uint32_t *dst = p.hc + (size_t)f * nb * p.n + x0 + col;
+	/* (rolled loops: the register budget of this kernel is what lets it share a SIMD with K1) */
+	uint32_t *dst = p.hc + (size_t)f * nb * p.n + x0 + lane;
+	const int sh = (lane & 32) ? 16 : 0;
 	if (cpb == 1) {
-		for (int b = row; b < nb; b += 16)
-			dst[(size_t)b * p.n] = h[b * 16 + col];
+#pragma unroll 1
+		for (int b = wv; b < nb; b += 4)
+			dst[(size_t)b * p.n] = (h[b * 32 + hcol] >> sh) & 0xffffu;
 	} else {
-		for (int b = row; b < nb; b += 16) {
-			const uint32_t v = h[b * 16 + col];
+#pragma unroll 1
+		for (int b = wv; b < nb; b += 4) {
+			const uint32_t v = (h[b * 32 + hcol] >> sh) & 0xffffu;
 			if (v)
 				atomicAdd(&dst[(size_t)b * p.n], v);
 		}
@@ -1189,7 +1229,7 @@ void k2_count(const K2Params p)
 
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
-	hipLaunchKernelGGL(k2_count, dim3((p.n / 16), n_chunks), dim3(256), (size_t)p.n_bins * 16 * sizeof(uint32_t), s, p);
+	hipLaunchKernelGGL(k2_count, dim3((p.n / 64), n_chunks), dim3(256), (size_t)p.n_bins * 32 * sizeof(uint32_t), s, p);
 	return hipGetLastError();
 }
 
@@ -1222,6 +1262,10 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s)
 /* K3: state update                                                          */
 /* ------------------------------------------------------------------------ */
 
+/* MODE 0: 16-bit slab-major counts + LDS (d, e) table; 1: 32-bit counts + (d, e) table in memory;
+ * 2: 32-bit counts, (d, e) evaluated per cell (batches beyond the table).  Separate instantiations keep
+ * the common one (0) at a register budget that lets it share a SIMD with K1. */
+template <int MODE>
 __global__ __launch_bounds__(256)
 void k3_merge(const K3Params p)
 {
@@ -1229,19 +1273,22 @@ void k3_merge(const K3Params p)
 	const int gid = blockIdx.x * 256 + threadIdx.x;
 	const float fbatch = (float)p.batch;
 
-	if (p.hc16) {
-		/* 16-bit slab-major counts: thread gid = (slab, bin, col) reads 2 B per batch, 8 batches in
-		 * flight; the (d, e) table sits in LDS (one dependent lookup per batch per cell). */
+	if (MODE == 0) {
+		/* 16-bit slab-major counts as K2 leaves them ([slab of 64 columns][bin][32] dwords, columns
+		 * c and c + 32 in the low / high half): thread gid reads the gid-th 16-bit word of a batch
+		 * (2 B per batch, 8 batches in flight); the (d, e) table sits in LDS (one dependent lookup
+		 * per batch per cell). */
 		__shared__ float2 rise_lds[1025];
 		for (int i = threadIdx.x; i <= p.batch && i < 1025; i += 256)
 			rise_lds[i] = p.rise[i];
 		__syncthreads();
 		if (gid < cells) {
 			const int nb = p.n_bins;
-			const int slab = gid / (nb * 16);
-			const int rem = gid - slab * nb * 16;
-			const int bin = rem >> 4, col = rem & 15;
-			const int hidx = bin * p.n + slab * 16 + col;
+			const int slab = gid / (nb * 64);
+			const int rem = gid - slab * nb * 64;
+			const int bin = rem >> 6;
+			const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
+			const int hidx = bin * p.n + slab * 64 + col;
 			float hv = p.hist[hidx];
 			int f = 0;
 			uint32_t last = 0;
@@ -1275,15 +1322,15 @@ void k3_merge(const K3Params p)
 			p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers) */
 		}
 	}
-	if (p.hc16) {
+	if (MODE == 0) {
 		/* cells handled above */
-	} else 	if (gid < cells) {
+	} else if (gid < cells) {
 		/* one (bin, x) cell; batches applied in order (display.cl:217-254).
 		 * d and e of display.cl:241-245 depend only on the hit count: with a table
 		 * rise[hc] = (d, e) (host-computed with the same powf the oracle uses) the update
 		 * is a lookup and display.cl:247,250. */
 		float hv = p.hist[gid];
-		if (p.rise) {
+		if (MODE == 1) {
 			/* 8 batches of counts in flight per thread: the loop is otherwise one dependent
 			 * HBM/L2 round trip per batch */
 			int f = 0;
@@ -1357,7 +1404,13 @@ void k3_merge(const K3Params p)
 hipError_t launch_k3(const K3Params &p, hipStream_t s)
 {
 	const int threads = p.n_bins * p.n + p.n;
-	hipLaunchKernelGGL(k3_merge, dim3((threads + 255) / 256), dim3(256), 0, s, p);
+	const dim3 grid((threads + 255) / 256);
+	if (p.hc16)
+		hipLaunchKernelGGL(k3_merge<0>, grid, dim3(256), 0, s, p);
+	else if (p.rise)
+		hipLaunchKernelGGL(k3_merge<1>, grid, dim3(256), 0, s, p);
+	else
+		hipLaunchKernelGGL(k3_merge<2>, grid, dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 

@@ -134,8 +134,10 @@ int fosphor_amd_merge(struct fosphor *self, int total_batch);
 
 /* ---- measurement ---------------------------------------------------------- */
 
-/* When enabled, every K1/K2/K3 launch is bracketed by hipEvents on the
- * instance's stream.  fosphor_amd_kernel_times synchronises, returns the summed
+/* enable = 1: every K1/K2/K3 launch is bracketed by hipEvents on the stream it
+ * runs on; enable = 2: K1 launches only (events beside K2/K3 lengthen the
+ * count/merge streams' critical path by a few microseconds per launch);
+ * 0: off.  fosphor_amd_kernel_times synchronises, returns the summed
  * milliseconds and launch counts per kernel since the last call, and resets. */
 void fosphor_amd_profile(struct fosphor *self, int enable);
 int  fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3]);

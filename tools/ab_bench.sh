@@ -9,6 +9,7 @@ CSRC=$ROOT/gr-fosphor_amd/csrc
 names=()
 for spec in "$@"; do
 	name=${spec%%:*}; flags=${spec#*:}
+	if [ "$flags" = "PREBUILT" ]; then names+=("$name"); continue; fi	# build/ab/lib_$name.so already there
 	hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -fPIC -Wno-unused-function $flags -x hip -shared \
 		-o "$ROOT/build/ab/lib_$name.so" $CSRC/fosphor_kernels.hip $CSRC/fosphor_api.cpp $CSRC/fosphor_render.cpp $CSRC/fosphor_sink.cpp \
 		-Rpass-analysis=kernel-resource-usage 2>&1 | grep -A6 "${AB_KERNEL:-k1v2_fft_binILb0}" | grep -E "VGPRs:|Scratch|Occupancy" | tr '\n' ' ' | sed "s/^/[$name] /"; echo
