@@ -339,6 +339,9 @@ void k1_fft_bin(const K1Params p)
 	const int wv     = threadIdx.x >> 6;
 	const int ntiles = p.total / p.tile;
 	const int stride = gridDim.x * 4;		/* waves in the grid */
+#if K1_TIMING
+	const long long t_wave_start = wall_clock64();	/* 100 MHz, common to all CUs */
+#endif
 	int tile = blockIdx.x * 4 + wv;
 	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
 
@@ -608,6 +611,9 @@ void k1_fft_bin(const K1Params p)
 		const int w = blockIdx.x * 4 + wv;
 		for (int i = 0; i < 8; i++)
 			p.dbg[w * 8 + i] = tacc[i];
+		/* wave lifetime on the common clock replaces the two near-empty phase slots */
+		p.dbg[w * 8 + 3] = t_wave_start;
+		p.dbg[w * 8 + 5] = wall_clock64();
 	}
 #endif
 }
@@ -1044,8 +1050,11 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		return hipGetLastError();
 	}
 	int blocks = (tiles + 3) / 4;
-	if (blocks > kK1MaxBlocks)
-		blocks = kK1MaxBlocks;		/* persistent: 2 work-groups per CU */
+	/* FOSPHOR_AMD_K1_BLOCKS: debugging aid (e.g. 256 = one wave per SIMD, for phase timing) */
+	static const int max_blocks = [] { const char *e = getenv("FOSPHOR_AMD_K1_BLOCKS"); const int v = e ? atoi(e) : 0;
+	                                   return (v > 0 && v < kK1MaxBlocks) ? v : kK1MaxBlocks; }();
+	if (blocks > max_blocks)
+		blocks = max_blocks;		/* persistent: 2 work-groups per CU */
 	if (p.fft_out)
 		hipLaunchKernelGGL(k1_fft_bin<true>, dim3(blocks), dim3(256), 0, s, p);
 	else
