@@ -135,7 +135,7 @@ def main():
                 if rv:
                     raise RuntimeError("process_device -> %d" % rv)
             else:
-                sf.frame(view, nb * BATCH * world, overlap=True)
+                sf.frame(view, nb * BATCH * world, overlap=True, wait_producer=False)	# IQ was generated before the warm-up
             pos += nb
             done += nb
         if sf is not None:
@@ -156,6 +156,7 @@ def main():
         f.profile(2)
     t0 = time.perf_counter()
     run_steps(args.steps, pos)
+    t_submit = time.perf_counter() - t0		# host time to queue everything (host-bound if ~ elapsed)
     sync()
     elapsed = time.perf_counter() - t0
     ms, launches = f.kernel_times()
@@ -221,6 +222,7 @@ def main():
                 "workload": "C2: 1024-pt FFT, batch=1024 spectra/step/GPU, 1024x%d histogram + waterfall" % args.bins,
                 "mode": mode, "batches_per_launch": F, "ring_batches": ring,
                 "input": "white complex Gaussian sigma=0.05, fp32 IQ resident in HBM (%d MiB ring)" % (ring * 8),
+                "host_submit_fraction": t_submit / elapsed,
                 "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d steps" % F,
             },
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,

@@ -581,11 +581,19 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	const int cpb = batch / chunk;
 	const size_t cells = (size_t)self->n_bins * self->n;
 
+	/* One batch of several chunks (the time shard of a display frame): K2 leaves per-chunk packed
+	 * 16-bit slabs in the upper half of d_hc (no zeroing, no global atomics) and k2c_sum adds them
+	 * into the 32-bit slot.  Needs whole 1024-spectrum chunks and room for cpb slabs. */
+	const int sum16 = !use16 && n_batches == 1 && chunk == 1024 && cpb > 1 && cpb <= self->max_batches &&
+	                  self->max_batches >= 4 && !getenv("FOSPHOR_AMD_NO_SUM16");
+
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
 	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch))
 	          ? (uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
+	if (sum16)
+		k2.hc16 = (uint16_t *)self->d_hc + (size_t)self->max_batches * cells;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
@@ -598,16 +606,23 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	} else {
 		k2.chunk_sum = self->d_chunk_sum;
 		k2.chunk_max = self->d_chunk_max;
-		HIP_TRY(hipMemsetAsync(k2.hc, 0, sizeof(uint32_t) * cells * n_batches, st), "zero hit counts");
+		if (!sum16)
+			HIP_TRY(hipMemsetAsync(k2.hc, 0, sizeof(uint32_t) * cells * n_batches, st), "zero hit counts");
 	}
 	prof_begin(self, 1, st);
 	HIP_TRY(launch_k2(k2, n_batches * cpb, st), "launch count");
 	if (cpb > 1) {
+		memset(&k2b, 0, sizeof(k2b));
 		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
 		k2b.live_sum = self->d_live_sum + (size_t)lslot * self->n;
 		k2b.vmax = self->d_vmax + (size_t)lslot * self->n;
 		k2b.n_batches = n_batches; k2b.cpb = cpb; k2b.n = self->n;
-		HIP_TRY(launch_k2b(k2b, st), "launch chunk reduce");
+		if (sum16) {
+			k2b.hc16 = k2.hc16; k2b.hc = k2.hc; k2b.n_bins = self->n_bins;
+			HIP_TRY(launch_k2c(k2b, st), "launch chunk sum");
+		} else {
+			HIP_TRY(launch_k2b(k2b, st), "launch chunk reduce");
+		}
 	}
 	prof_end(self, st);
 	return 0;

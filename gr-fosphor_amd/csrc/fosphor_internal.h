@@ -63,7 +63,7 @@ struct K2Params {
 	const uint32_t *bins;		/* [total/4][N] */
 	const float2   *partial;	/* [total/tile][N] */
 	uint32_t *hc;			/* [n_batches][n_bins][N] */
-	uint16_t *hc16;			/* or (batch <= 1024, one chunk per batch): [n_batches][N/64][n_bins][32] dwords,
+	uint16_t *hc16;			/* or (chunk <= 1024): per chunk [n_chunks][N/64][n_bins][32] dwords,
 					 * columns c and c + 32 of the slab in the low / high half */
 	float    *chunk_sum;		/* [n_chunks][N] */
 	float    *chunk_max;		/* [n_chunks][N] */
@@ -84,6 +84,10 @@ struct K2bParams {
 	const float *chunk_sum, *chunk_max;	/* [n_batches * cpb][N] */
 	float *live_sum, *vmax;			/* [n_batches][N] */
 	int   n_batches, cpb, n;
+	/* k2c_sum only (one batch made of cpb chunks whose counts K2 left as packed 16-bit slabs): */
+	const uint16_t *hc16;			/* [cpb][N/64][n_bins][32] dwords */
+	uint32_t *hc;				/* [n_bins][N] sums */
+	int   n_bins;
 };
 
 /* K3: histogram rise/decay, live EMA, max-hold */
@@ -104,6 +108,7 @@ struct K3Params {
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s);
 hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
+hipError_t launch_k2c(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,

@@ -1213,7 +1213,7 @@ void k2_count(const K2Params p)
 	if (p.hc16) {
 		/* the LDS image as it is: [bin][32] packed pairs, one contiguous block per work-group
 		 * (32 KiB at 256 bins); K3 unpacks */
-		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)f * (p.n / 64) + blockIdx.x) * nb * 32;
+		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)c * (p.n / 64) + blockIdx.x) * nb * 32;
 #pragma unroll 2
 		for (int i = tid; i < nb * 32; i += 256)
 			d[i] = h[i];
@@ -1264,6 +1264,75 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s)
 {
 	const int threads = p.n_batches * p.n;
 	hipLaunchKernelGGL(k2b_reduce, dim3((threads + 255) / 256), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+/* One batch of cpb chunks (the time shard of a display frame): sum the chunks' packed 16-bit
+ * count slabs into the 32-bit [bin][x] array the all-reduce and K3 work on, and reduce the float
+ * partials in the same fixed order as k2b_reduce.  Integer sums: exact, order-independent. */
+__global__ __launch_bounds__(256)
+void k2c_sum(const K2bParams p)
+{
+	const int pairs = p.n_bins * p.n / 2;		/* dwords per chunk slab set: columns c, c + 32 packed */
+	const int cells = pairs;			/* thread index space: one thread per packed pair */
+	const int gid = blockIdx.x * 256 + threadIdx.x;
+	if (gid < pairs) {
+		const int nb = p.n_bins;
+		const int slab = gid / (nb * 32);
+		const int rem = gid - slab * nb * 32;
+		const int bin = rem >> 5, hcol = rem & 31;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.hc16) + gid;
+		uint32_t lo = 0, hi = 0;
+		int c = 0;
+		for (; c + 8 <= p.cpb; c += 8) {
+			uint32_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++)
+				v[u] = __builtin_nontemporal_load(&src[(size_t)(c + u) * pairs]);
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				lo += v[u] & 0xffffu;
+				hi += v[u] >> 16;
+			}
+		}
+		for (; c < p.cpb; c++) {
+			const uint32_t v = src[(size_t)c * pairs];
+			lo += v & 0xffffu;
+			hi += v >> 16;
+		}
+		uint32_t *dst = p.hc + bin * p.n + slab * 64 + hcol;
+		dst[0]  = lo;
+		dst[32] = hi;
+	} else if (gid < cells + p.n) {
+		const int x = gid - cells;
+		float s = 0.0f, m = -1000.0f;
+		int c = 0;
+		for (; c + 8 <= p.cpb; c += 8) {
+			float a[8], b[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				a[u] = p.chunk_sum[(size_t)(c + u) * p.n + x];
+				b[u] = p.chunk_max[(size_t)(c + u) * p.n + x];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++) {		/* same order as k2b_reduce */
+				s += a[u];
+				m = (m < b[u]) ? b[u] : m;
+			}
+		}
+		for (; c < p.cpb; c++) {
+			s += p.chunk_sum[(size_t)c * p.n + x];
+			m = (m < p.chunk_max[(size_t)c * p.n + x]) ? p.chunk_max[(size_t)c * p.n + x] : m;
+		}
+		p.live_sum[x] = s;
+		p.vmax[x] = m;
+	}
+}
+
+hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
+{
+	const int threads = p.n_bins * p.n / 2 + p.n;
+	hipLaunchKernelGGL(k2c_sum, dim3((threads + 255) / 256), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 

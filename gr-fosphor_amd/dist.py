@@ -108,12 +108,15 @@ class ShardedFosphor:
             raise RuntimeError("merge -> %d" % rv)
         self.pending = None
 
-    def frame(self, d_samples_local, total_batch, overlap=False):
+    def frame(self, d_samples_local, total_batch, overlap=False, wait_producer=True):
+        """wait_producer=False: the caller guarantees d_samples_local is complete (saves the event
+        record + wait between the caller's stream and the FFT stream, two queue packets per frame)."""
         torch = self.torch
         off, n = shard_range(total_batch, self.rank, self.world)
         slot = self.k & 1
         self.k += 1
-        self.stream.wait_stream(torch.cuda.current_stream())	# the caller's producer of d_samples_local
+        if wait_producer:
+            self.stream.wait_stream(torch.cuda.current_stream())	# the caller's producer of d_samples_local
         with torch.cuda.stream(self.stream):
             self.f.set_partial_slot(slot)
             rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)	# K1 here, K2 on stream_b

@@ -370,6 +370,50 @@ def test_sharded_batch_equals_single_launch(amd, torch_cuda, oracle_built):
         fr.close()
 
 
+@pytest.mark.parametrize("no_sum16", ["", "1"])
+def test_sharded_frame_many_chunks(amd, torch_cuda, oracle_built, monkeypatch, no_sum16):
+    """A time shard of several 1024-spectrum chunks (what a display frame is on every rank): two 'ranks'
+    take 4096 spectra each of one 8192-spectrum batch.  The shard's hit counts go through per-chunk
+    packed 16-bit slabs + k2c_sum (default) or through 32-bit global atomics (FOSPHOR_AMD_NO_SUM16=1);
+    both must give the oracle's counts for the whole batch."""
+    torch = torch_cuda
+    if no_sum16:
+        monkeypatch.setenv("FOSPHOR_AMD_NO_SUM16", "1")
+    else:
+        monkeypatch.delenv("FOSPHOR_AMD_NO_SUM16", raising=False)
+    total = 8192
+    x = add_tone(gaussian_iq(total * 1024, 53), 0.04, -0.12)
+    d = torch.from_numpy(x).cuda()
+    ranks = [amd.Fosphor(max_spectra=total // 2, n_bins=256) for _ in range(2)]
+    parts = []
+    for r, fr in enumerate(ranks):
+        off = r * (total // 2)
+        assert fr.accumulate_device(d[off * 1024:(off + total // 2) * 1024], total // 2, off, total) == 0
+        fr.finish()
+        parts.append(fr.partials())
+    from gr_fosphor_amd.dist import wrap_device_array
+    hc = [wrap_device_array(p.d_hc, (p.n_hc,), torch.int32) for p in parts]
+    ls = [wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32) for p in parts]
+    mx = [wrap_device_array(p.d_max, (p.n_cols,), torch.float32) for p in parts]
+    hc_sum, ls_sum, mx_max = hc[0] + hc[1], ls[0] + ls[1], torch.maximum(mx[0], mx[1])
+    for r in range(2):
+        hc[r].copy_(hc_sum); ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
+    torch.cuda.synchronize()
+    for fr in ranks:
+        assert fr.merge(total) == 0
+    o = Oracle(n_bins=256)
+    assert o.process(x, strict=False, nthreads=8) == 0
+    for fr in ranks:
+        assert np.array_equal(fr.hitcount, o.hitcount.T)
+        assert int(fr.hitcount.sum()) == total * 1024
+        assert_hist_close(fr.histogram, o.histogram, "frame histogram")
+        assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "frame live")
+        assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "frame max-hold")
+    assert_close(ranks[1].waterfall, o.waterfall, "frame waterfall (rank 1 rows)")
+    for fr in ranks:
+        fr.close()
+
+
 def overlap_cc_reference(x, wlen, overlap):
     """numpy restatement of lib/overlap_cc_impl.cc:64-79: windows of wlen samples whose starts
     advance wlen/overlap input samples, concatenated."""
