@@ -13,8 +13,8 @@ CSRC    := gr-fosphor_amd/csrc
 LIB     := gr-fosphor_amd/libfosphor_amd.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -pthread -Wall -Wno-unused-function
 
-SRCS := $(CSRC)/fosphor_kernels.hip $(CSRC)/fosphor_api.cpp $(CSRC)/fosphor_render.cpp $(CSRC)/fosphor_sink.cpp
-HDRS := $(CSRC)/fosphor_internal.h include/fosphor.h include/fosphor_amd.h include/fosphor_amd_sink.h include/fosphor_portable_math.h
+SRCS := $(CSRC)/fosphor_kernels.hip $(CSRC)/fosphor_cmap.hip $(CSRC)/fosphor_api.cpp $(CSRC)/fosphor_render.cpp $(CSRC)/fosphor_sink.cpp
+HDRS := $(CSRC)/fosphor_internal.h include/fosphor.h include/fosphor_amd.h include/fosphor_amd_sink.h include/fosphor_amd_cmap.h include/fosphor_amd_axis.h include/fosphor_portable_math.h
 
 all: $(LIB)
 

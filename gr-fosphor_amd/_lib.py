@@ -48,6 +48,13 @@ class Render(C.Structure):
 
 
 # every exported entry point: name -> (restype, argtypes)
+class FreqAxis(C.Structure):
+    """struct fosphor_amd_freq_axis (= the reference's struct freq_axis, axis.h:20-30)"""
+    _fields_ = [("center", C.c_double), ("span", C.c_double), ("step", C.c_double), ("mode", C.c_int),
+                ("abs_fmt", C.c_char * 16), ("abs_scale", C.c_double), ("rel_fmt", C.c_char * 16),
+                ("rel_step", C.c_double)]
+
+
 SIGNATURES = {
     # include/fosphor.h
     "fosphor_init": (C.c_void_p, []),
@@ -89,6 +96,15 @@ SIGNATURES = {
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
+    # include/fosphor_amd_axis.h
+    "fosphor_amd_freq_axis_build": (None, [C.c_void_p, C.c_double, C.c_double, C.c_int]),
+    "fosphor_amd_freq_axis_render": (None, [C.c_void_p, C.c_char_p, C.c_int]),
+    "fosphor_amd_freq_labels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "fosphor_amd_power_labels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int * 11)]),
+    # include/fosphor_amd_cmap.h
+    "fosphor_amd_cmap_generate": (C.c_int, [C.c_int, C.c_void_p, C.c_int]),
+    "fosphor_amd_colorize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                       C.c_int, C.c_void_p]),
     # include/fosphor_amd_sink.h
     "fosphor_amd_process_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "fosphor_amd_wait_upload": (C.c_int, [C.c_void_p]),

@@ -135,6 +135,25 @@ class Fosphor:
     def waterfall_pos(self):
         return self.buffers().waterfall_pos
 
+    def colorize(self, image, palette=None, scale=None, offset=None, rows=None):
+        """RGBA8 picture of the waterfall (image=0, newest row first) or the histogram (image=1,
+        highest bin first), fft-shifted, as a torch uint8 tensor [rows][N][4] on the device.
+        palette: numpy uint32[n] (host) or None for the reference's 256-entry palette of that image;
+        scale/offset None: the reference's values (include/fosphor_amd_cmap.h)."""
+        import torch
+        if rows is None:
+            rows = self.wf_rows if image == 0 else self.n_bins
+        out = torch.empty((rows, self.n), dtype=torch.int32, device="cuda")
+        if palette is not None:
+            palette = np.ascontiguousarray(palette, dtype=np.uint32)
+        defaults = scale is None and offset is None
+        rv = self.L.fosphor_amd_colorize(self.h, int(image), palette.ctypes.data if palette is not None else None,
+                                         palette.size if palette is not None else 0, 1 if defaults else 0,
+                                         float(scale or 0.0), float(offset or 0.0), int(rows), out.data_ptr())
+        if rv:
+            raise RuntimeError("fosphor_amd_colorize -> %d" % rv)
+        return out.view(torch.uint8).reshape(rows, self.n, 4)
+
     @property
     def histo_scale(self):
         return self.buffers().histo_scale

@@ -92,6 +92,7 @@ struct fosphor
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
 	long long *d_dbg;			/* K1_TIMING builds only (FOSPHOR_AMD_K1_TIMING=1) */
+	uint32_t *d_palette;			/* colour-map scratch (fosphor_cmap.hip), allocated on first use */
 	float2   *d_rise;			/* [kRiseMax+1] (d, e) per hit count */
 	float2   *h_rise;			/* pinned */
 	int       rise_batch;			/* batch the table was built for (0 = none) */
@@ -230,6 +231,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
+	(void)hipFree(self->d_palette);
 	(void)hipFree(self->d_dbg);
 	if (self->h_rise) (void)hipHostFree(self->h_rise);
 	for (int i = 0; i < 2; i++) {
@@ -1092,6 +1094,21 @@ extern "C" void fosphor_amd_priv_ranges(struct fosphor *self, int *db_ref, int *
 	*db_per_div = self->power.db_per_div;
 	*center = self->frequency.center;
 	*span = self->frequency.span;
+}
+
+/* private accessors for fosphor_cmap.hip */
+extern "C" int fosphor_amd_priv_palette(struct fosphor *self, int n, uint32_t **d_palette)
+{
+	if (!self->d_palette && hipMalloc((void **)&self->d_palette, sizeof(uint32_t) * n) != hipSuccess)
+		return -EIO;
+	*d_palette = self->d_palette;
+	return 0;
+}
+
+extern "C" void fosphor_amd_priv_power(struct fosphor *self, float *scale, float *offset)
+{
+	*scale = self->power.scale;
+	*offset = self->power.offset;
 }
 
 /* ------------------------------------------------------------------------ */

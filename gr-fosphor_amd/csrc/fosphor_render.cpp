@@ -187,3 +187,127 @@ extern "C" int fosphor_render_pos_inside(struct fosphor_render *r, int x, int y)
 		mask |= 4;
 	return mask;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Axis labels (include/fosphor_amd_axis.h)                                   */
+/* ------------------------------------------------------------------------ */
+
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fosphor_amd_axis.h"
+
+namespace {
+
+/* Power of 1000 by which a value is divided so that at most `digits` digits stay in front of the
+ * decimal point, as an exponent of ten (0, 3, 6, ...).  axis.c:32-47: the magnitude is taken
+ * with the FLOAT log10 of the value and truncated towards zero. */
+int si_exponent(double val, int digits)
+{
+	const int mag = (int)log10f((float)fabs(val));
+	return (mag >= digits) ? 3 * ((mag - digits + 3) / 3) : 0;
+}
+
+const char *si_prefix(int exp10)
+{
+	static const char *const names[5] = { "", "k", "M", "G", "T" };	/* ' ' is dropped by the callers, axis.c:99-100 */
+	return names[exp10 / 3];
+}
+
+/* decimals needed to print val exactly, up to 21; -1 if none does (axis.c:49-61) */
+int decimals_needed(double val)
+{
+	for (int c = 0; c < 22; c++) {
+		const double v = val * pow(10, c);
+		if (fabs(v - round(v)) == 0.0)
+			return c;
+	}
+	return -1;
+}
+
+} // namespace
+
+extern "C" void fosphor_amd_freq_axis_build(struct fosphor_amd_freq_axis *fx, double center, double span, int n_div)
+{
+	fx->center = center;
+	fx->span   = span;
+	fx->step   = span / n_div;
+
+	/* count / relative / absolute, axis.c:71-80 (float log10 of the doubles, as there) */
+	if (span == 0.0)
+		fx->mode = 0;
+	else if (center == 0.0)
+		fx->mode = 1;
+	else
+		fx->mode = (floor(log10f((float)fx->step)) < floor(log10f((float)fx->center)) - 4) ? 1 : 2;
+
+	if (center != 0.0) {					/* axis.c:83-113 */
+		const double hi = fabs(center + span / 2.0), lo = fabs(center - span / 2.0);
+		const double big = hi > lo ? hi : lo;
+		const int e = si_exponent(big, 4);
+		unsigned int x, y, z;
+
+		fx->abs_scale = 1.0 / powf(10.0, e);
+		x = (int)floor(log10f((float)big)) - e + 1;
+		y = decimals_needed(fx->center * fx->abs_scale);
+		z = decimals_needed(fx->step * fx->abs_scale);
+		if (z > y) y = z;
+		if (x + y > 6) y = 6 - x;
+		snprintf(fx->abs_fmt, sizeof(fx->abs_fmt), "%%.%dlf%s", y, si_prefix(e));
+	}
+
+	if (fx->mode == 1) {					/* axis.c:116-135 */
+		const double max_dev = fx->step * 5;
+		const int e = si_exponent(max_dev, 3);
+		unsigned int x, y;
+
+		fx->rel_step = fx->step / powf(10.0, e);
+		x = (int)floor(log10f((float)max_dev)) - e + 1;
+		y = decimals_needed(fx->rel_step);
+		if (x + y > 4) y = 4 - x;
+		snprintf(fx->rel_fmt, sizeof(fx->rel_fmt), "%%+.%dlf%s", y, si_prefix(e));
+	}
+}
+
+extern "C" void fosphor_amd_freq_axis_render(const struct fosphor_amd_freq_axis *fx, char *str, int step)
+{
+	if (step && fx->mode == 0)				/* axis.c:141-145 */
+		snprintf(str, 32, "%+d", step);
+	else if (!step && fx->center == 0.0)			/* :147-151 */
+		snprintf(str, 32, "0");
+	else if (step && fx->mode == 1)				/* :153-157 */
+		snprintf(str, 32, fx->rel_fmt, step * fx->rel_step);
+	else							/* :159-160 */
+		snprintf(str, 32, fx->abs_fmt, (fx->center + step * fx->step) * fx->abs_scale);
+}
+
+extern "C" int fosphor_amd_freq_labels(struct fosphor *self, const struct fosphor_render *render,
+                                       char (*labels)[32], int max_labels)
+{
+	struct fosphor_amd_freq_axis fx;
+	int a, b; double c, s;
+	if (!self || !render || !labels || render->freq_n_div < 1 || max_labels < render->freq_n_div + 1)
+		return -EINVAL;
+	fosphor_amd_priv_ranges(self, &a, &b, &c, &s);
+	if (render->freq_center != 0.5f || render->freq_span != 1.0f) {	/* gl.c:555-565 */
+		const view v = freq_view(self, render);
+		fosphor_amd_freq_axis_build(&fx, v.center, v.span, render->freq_n_div);
+	} else {								/* gl.c:566-575: the numbers as given */
+		fosphor_amd_freq_axis_build(&fx, c, s, render->freq_n_div);
+	}
+	for (int i = 0; i <= render->freq_n_div; i++)
+		fosphor_amd_freq_axis_render(&fx, labels[i], i - render->freq_n_div / 2);	/* gl.c:640-643 */
+	return render->freq_n_div + 1;
+}
+
+extern "C" int fosphor_amd_power_labels(struct fosphor *self, int db[11])
+{
+	int db_ref, db_div; double c, s;
+	if (!self || !db)
+		return -EINVAL;
+	fosphor_amd_priv_ranges(self, &db_ref, &db_div, &c, &s);
+	for (int i = 0; i < 11; i++)
+		db[i] = db_ref - (10 - i) * db_div;			/* gl.c:604 */
+	return 0;
+}

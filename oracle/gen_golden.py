@@ -71,7 +71,7 @@ def main(argv):
     os.makedirs(OUT, exist_ok=True)
     meta_path = os.path.join(OUT, "golden_meta.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
-    names = argv or list(gc.CASES)
+    names = [a for a in argv if a in gc.CASES] if argv else list(gc.CASES)
 
     for name in names:
         spec = gc.CASES[name]
@@ -126,8 +126,50 @@ def main(argv):
         np.savez_compressed(os.path.join(OUT, "fft512.npz"), x=x, win=gc.hann512(), fft=y)
         meta["fft512"] = {"sha_fft": sha(y)}
 
+    if not argv or "cmap" in argv:
+        # palettes straight from the reference's gl_cmap_gen.c (oracle/_ref/libcmap_ref.so)
+        import ctypes as C
+        L = C.CDLL(os.path.join(HERE, "_ref", "libcmap_ref.so"))
+        arrays = {}
+        for fn in ("histogram", "waterfall", "prog"):
+            f = getattr(L, "fosphor_gl_cmap_" + fn)
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+            for n in (256, 64, 1000):		# 256 is what gl.c:265-268 asks for
+                buf = np.zeros(n, np.uint32)
+                assert f(buf.ctypes.data, n, None) == 0
+                arrays["%s_%d" % (fn, n)] = buf
+        np.savez_compressed(os.path.join(OUT, "cmap_palettes.npz"), **arrays)
+        meta["cmap_palettes"] = {k: sha(v) for k, v in arrays.items()}
+
+    if not argv or "axis" in argv:
+        # frequency-axis labels straight from the reference's axis.c (oracle/_ref/libaxis_ref.so)
+        import ctypes as C
+
+        class FreqAxis(C.Structure):		# axis.h:20-30
+            _fields_ = [("center", C.c_double), ("span", C.c_double), ("step", C.c_double), ("mode", C.c_int),
+                        ("abs_fmt", C.c_char * 16), ("abs_scale", C.c_double), ("rel_fmt", C.c_char * 16),
+                        ("rel_step", C.c_double)]
+        L = C.CDLL(os.path.join(HERE, "_ref", "libaxis_ref.so"))
+        L.freq_axis_build.argtypes = [C.POINTER(FreqAxis), C.c_double, C.c_double, C.c_int]
+        L.freq_axis_render.argtypes = [C.POINTER(FreqAxis), C.c_char_p, C.c_int]
+        cases = []
+        for center, span, n_div in gc.AXIS_CASES:
+            fx = FreqAxis()
+            L.freq_axis_build(C.byref(fx), center, span, n_div)
+            labels = []
+            for step in range(-(n_div // 2), n_div - n_div // 2 + 1):
+                buf = C.create_string_buffer(64)
+                L.freq_axis_render(C.byref(fx), buf, step)
+                labels.append(buf.value.decode())
+            cases.append(dict(center=center, span=span, n_div=n_div, mode=fx.mode,
+                              abs_fmt=fx.abs_fmt.decode() if center != 0.0 else None,
+                              abs_scale=fx.abs_scale if center != 0.0 else None,
+                              rel_fmt=fx.rel_fmt.decode() if fx.mode == 1 else None,
+                              rel_step=fx.rel_step if fx.mode == 1 else None, labels=labels))
+        json.dump(cases, open(os.path.join(OUT, "axis_labels.json"), "w"), indent=1)
+
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main([a for a in sys.argv[1:] if a in gc.CASES or a == "fft512"])
+    main([a for a in sys.argv[1:] if a in gc.CASES or a in ("fft512", "cmap", "axis")])

@@ -97,3 +97,12 @@ FFT512_SEED = 512
 
 def fft512_input():
     return gaussian_iq(4 * 512, FFT512_SEED, sigma=1.0)
+
+
+# Frequency-axis cases for the label formatter (axis.c:63-162): (center Hz, span Hz, n_div)
+AXIS_CASES = [
+    (100e6, 2e6, 10), (0.0, 1.0, 10), (0.0, 2e6, 10), (100e6, 0.0, 10), (2.4e9, 20e6, 10), (1e3, 100.0, 10),
+    (433.92e6, 250e3, 10), (10.7e6, 48e3, 8), (-5e6, 1e6, 10), (1.57542e9, 4.092e6, 10), (145.8e6, 12.5e3, 10),
+    (7.1e6, 192e3, 12), (28.074e6, 3e3, 6), (5.8e9, 160e6, 10), (1.0, 0.5, 10), (99999.0, 10.0, 10),
+    (1e12, 1e9, 10), (433.92e6, 250e3, 7), (0.0, 56e6, 14), (88.3e6, 3.2e6, 16),
+]
