@@ -15,7 +15,7 @@ class Config(C.Structure):
     _fields_ = [("fft_len_log", C.c_int), ("n_bins", C.c_int), ("wf_rows", C.c_int),
                 ("t0r", C.c_float), ("t0d", C.c_float), ("alpha", C.c_float),
                 ("device", C.c_int), ("max_spectra", C.c_int), ("max_batches", C.c_int),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("iq_format", C.c_int)]
 
 
 class Buffers(C.Structure):

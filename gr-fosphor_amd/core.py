@@ -29,10 +29,11 @@ class Fosphor:
     """One fosphor instance (struct fosphor).  Reference geometry by default."""
 
     def __init__(self, n_bins=128, wf_rows=1024, fft_len_log=FFT_LEN_LOG, t0r=0.0, t0d=0.0, alpha=0.0,
-                 device=-1, max_spectra=1024, max_batches=0, stream=None):
+                 device=-1, max_spectra=1024, max_batches=0, stream=None, iq_fp16=False):
         self.L = _lib.load()
         cfg = _lib.Config(fft_len_log, n_bins, wf_rows, t0r, t0d, alpha, device, max_spectra, max_batches,
-                          C.c_void_p(stream) if stream else None)
+                          C.c_void_p(stream) if stream else None, 1 if iq_fp16 else 0)
+        self.iq_fp16 = bool(iq_fp16)
         self.h = self.L.fosphor_amd_init(C.byref(cfg))
         if not self.h:
             raise RuntimeError("fosphor_amd_init failed (see stderr); no CPU fallback exists")
@@ -53,7 +54,7 @@ class Fosphor:
     # ---- reference API ---------------------------------------------------
     def process(self, samples):
         """fosphor_process: host interleaved fp32 (re, im); returns 0 / -EINVAL / -EIO."""
-        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        x = np.ascontiguousarray(samples, dtype=np.float16 if self.iq_fp16 else np.float32).reshape(-1)
         return self.L.fosphor_process(self.h, x.ctypes.data, x.size // 2)
 
     def draw(self, render=None):

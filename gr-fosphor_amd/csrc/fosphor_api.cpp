@@ -36,7 +36,7 @@ using namespace fosphor_amd;
 
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
-static const int kMaxN = 8192;
+static const int kMaxN = 65536;
 static const int kSets = 2;		/* intermediate (bin index / partial) sets in rotation */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
@@ -49,6 +49,8 @@ struct fosphor
 	int tw_len, tw_off[8];
 	float t0r, t0d, alpha;
 	int max_spectra, max_batches;
+	int iq_half;				/* device IQ is fp16 pairs (N = 65536 only) */
+	size_t stage_samples;			/* capacity of one host staging slot, samples */
 
 	/* reference-visible settings (private.h:44-54) */
 	float fft_win[kMaxN];
@@ -98,7 +100,7 @@ struct fosphor
 	int       rise_batch;			/* batch the table was built for (0 = none) */
 	float     rise_t0r, rise_t0d;
 	int       slot;				/* partial-array slot used by accumulate/merge */
-	float2   *d_fft_tmp;			/* fosphor_amd_fft scratch is caller-provided; unused */
+	float2   *d_scratch;			/* N = 65536: [max_spectra][N] spectrum between the two FFT stages */
 
 	/* host->device staging for fosphor_process (pinned ring of 2) */
 	float2   *h_stage[2];
@@ -232,6 +234,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
 	(void)hipFree(self->d_palette);
+	(void)hipFree(self->d_scratch);
 	(void)hipFree(self->d_dbg);
 	if (self->h_rise) (void)hipHostFree(self->h_rise);
 	for (int i = 0; i < 2; i++) {
@@ -269,8 +272,17 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->max_batches = (cfg && cfg->max_batches > 0) ? cfg->max_batches
 	                    : (self->max_spectra / 1024 > 8 ? self->max_spectra / 1024 : 8);
 
-	if (self->log2n != 10 && self->log2n != 13) {
-		fprintf(stderr, "[!] fosphor_amd: fft_len_log=%d not supported (10 or 13)\n", self->log2n);
+	if (self->log2n != 10 && self->log2n != 13 && self->log2n != 16) {
+		fprintf(stderr, "[!] fosphor_amd: fft_len_log=%d not supported (10, 13 or 16)\n", self->log2n);
+		goto error;
+	}
+	self->iq_half = (cfg && cfg->iq_format == FOSPHOR_AMD_IQ_FP16);
+	if (cfg && cfg->iq_format != FOSPHOR_AMD_IQ_FP32 && cfg->iq_format != FOSPHOR_AMD_IQ_FP16) {
+		fprintf(stderr, "[!] fosphor_amd: iq_format=%d unknown\n", cfg->iq_format);
+		goto error;
+	}
+	if (self->iq_half && self->log2n != 16) {
+		fprintf(stderr, "[!] fosphor_amd: fp16 IQ is only implemented for fft_len_log=16\n");
 		goto error;
 	}
 	if (self->n_bins < 16 || self->n_bins > 512 || (self->n_bins & 15)) {
@@ -326,6 +338,10 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
+	if (self->log2n == 16)
+		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)self->max_spectra * self->n), "alloc stage scratch");
+	/* host staging slot: the reference's cap of 1024 spectra per call (cl.c:885), or this instance's */
+	self->stage_samples = (size_t)self->n * (self->max_spectra < 1024 ? self->max_spectra : 1024);
 	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
 	HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
 	for (int i = 0; i < 2; i++) {
@@ -566,7 +582,9 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->amb = 0.5f - delta0;
 	k1->kappa = kappa;
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
-	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : 3;
+	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : (self->log2n == 16 ? 4 : 3);
+	k1->scratch = self->d_scratch;
+	k1->iq_half = self->iq_half;
 	if (k1->variant == 1 && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
@@ -784,11 +802,12 @@ extern "C" int fosphor_amd_process_device_overlap(struct fosphor *self, const vo
 extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 {
 	int k;
+	const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
 
 	/* cl.c:882-886 */
 	if (len <= 0 || (len & ((16 * self->n) - 1)))
 		return -EINVAL;
-	if (len > (self->n * 1024))
+	if ((long long)len > (long long)self->n * 1024)
 		return -EINVAL;
 	if (len / self->n > self->max_spectra)
 		return -EINVAL;
@@ -799,14 +818,14 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	 * its H2D copy has completed. */
 	k = self->stage_idx;
 	if (!self->h_stage[k]) {
-		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sizeof(float2) * self->n * 1024, hipHostMallocDefault), "alloc pinned staging");
-		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * self->n * 1024), "alloc device staging");
+		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sample_bytes * self->stage_samples, hipHostMallocDefault), "alloc pinned staging");
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	} else {
 		HIP_TRY(hipEventSynchronize(self->stage_free[k]), "wait staging slot");
 	}
-	memcpy(self->h_stage[k], samples, sizeof(float2) * (size_t)len);
-	HIP_TRY(hipMemcpyAsync(self->d_stage[k], self->h_stage[k], sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples");
+	memcpy(self->h_stage[k], samples, sample_bytes * (size_t)len);
+	HIP_TRY(hipMemcpyAsync(self->d_stage[k], self->h_stage[k], sample_bytes * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples");
 	{
 		int rv = run(self, self->d_stage[k], 1, len / self->n);
 		/* the slot is free again once everything queued so far (copy + kernels reading
@@ -822,19 +841,20 @@ error:
 extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len)
 {
 	int k, rv;
+	const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
 
-	if (len <= 0 || (len & ((16 * self->n) - 1)) || len > (self->n * 1024) || len / self->n > self->max_spectra)
+	if (len <= 0 || (len & ((16 * self->n) - 1)) || (long long)len > (long long)self->n * 1024 || len / self->n > self->max_spectra)
 		return -EINVAL;		/* cl.c:882-886 */
 
 	k = self->stage_idx;
 	if (!self->d_stage[k]) {
-		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sizeof(float2) * self->n * 1024), "alloc device staging");
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	}
 	if (!self->upload_done)
 		HIP_TRY(hipEventCreateWithFlags(&self->upload_done, hipEventDisableTiming), "create upload event");
 	/* d_stage[k] was last read by a K1 queued earlier on the same stream: ordered by the stream */
-	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sizeof(float2) * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples (pinned)");
+	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sample_bytes * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples (pinned)");
 	HIP_TRY(hipEventRecord(self->upload_done, self->stream), "record upload");
 	rv = run(self, self->d_stage[k], 1, len / self->n);
 	self->stage_idx ^= 1;

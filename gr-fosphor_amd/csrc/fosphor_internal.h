@@ -41,6 +41,8 @@ struct K1Params {
 	float        *wf;		/* [wf_rows][N] */
 	float2       *fft_out;		/* test hook, or nullptr */
 	long long    *dbg;		/* K1_TIMING builds: [waves][8] cycle accumulators, or nullptr */
+	float2       *scratch;		/* variant 4: [total][N] intermediate spectrum between the two stages */
+	int   iq_half;			/* variant 4: the IQ stream is fp16 (re, im) pairs, 4 B per sample */
 	int   total;			/* spectra in this launch */
 	int   tile;			/* spectra per wave: 4, 8 or 16 */
 	int   wf_pos0, wf_mask;		/* ring position of spectrum 0, wf_rows-1 */
@@ -50,7 +52,8 @@ struct K1Params {
 	float amb;			/* confident when |v - rint(v)| + kappa |l2| <= amb */
 	float kappa;			/* v_log_f32 error bound per unit of |log2 s|, through the slope binA */
 	float w;			/* 1 - alpha */
-	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum; 3: general N (N/8 threads per spectrum) */
+	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum; 3: general N (N/8 threads per
+					 * spectrum, one LDS slab); 4: N = 65536 in two LDS stages */
 };
 
 /* K2: bin indices -> hit counts + live sum / max per column.

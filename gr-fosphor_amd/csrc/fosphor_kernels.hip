@@ -1018,8 +1018,270 @@ void k1big_fft_bin(const K1Params p)
 	}
 }
 
+/* ------------------------------------------------------------------------ */
+/* K1 for N = 65536: two LDS stages                                           */
+/* ------------------------------------------------------------------------ */
+/* The plan for N = 8^5 * 2 is five radix-8 Stockham passes (p = 1, 8, 64, 512, 4096) and the
+ * radix-2 pass (p = 32768), 8192 virtual work-items of 8 points (the generalisation of
+ * fft.cl:397-466 the oracle defines).  512 KiB per spectrum does not fit one CU's LDS, but the
+ * data flow of the plan factors:
+ *
+ *   stage A  passes 1-3 only mix inputs whose index is congruent mod 128: for each residue q they
+ *            ARE the three passes of a 512-point Stockham FFT (twiddles depend on p and k = i & (p-1)
+ *            only) on x[q + 128 m], m < 512, and leave their 512 results CONTIGUOUS at [512 q, 512 q + 512).
+ *            One work-group takes 16 adjacent residues (64-byte runs of fp16 IQ / 128-byte runs of fp32).
+ *   stage B  passes 4, 5 and the radix-2 pass only mix elements with the same offset k inside those
+ *            blocks: for each k < 512 a 128-point (8 x 8 x 2) transform over w[512 q + k], q < 128, whose
+ *            twiddle indices are k (p = 512), k + 512 jj4 (p = 4096) and k + 512 jj4 + 4096 jj5 (radix 2),
+ *            and whose outputs are columns k + 512 m, m < 128.  One work-group takes 32 adjacent k
+ *            (256-byte runs), and carries the same epilogue as the other K1 kernels.
+ *
+ * Between the stages the spectrum makes one round trip through HBM / the Infinity Cache as fp32
+ * (8 B per sample written and read).  Arithmetic: the same c_mul / dft8 / DFT2 as every other variant,
+ * hence the same bits as the oracle.  fp16 IQ is widened on load (exact). */
+template <bool HALF>
+__global__ __launch_bounds__(1024)
+void k1h_stage_a(const K1Params p)
+{
+	constexpr int N = 65536, QA = 16, M = 512, TS = 64, ROW = M + 1;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	v2f *buf = reinterpret_cast<v2f *>(smem_raw) + (threadIdx.x & (QA - 1)) * ROW;	/* this residue's row */
+	const int ql = threadIdx.x & (QA - 1);
+	const int i  = threadIdx.x >> 4;				/* sub-FFT work-item, 0..63 */
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const int nwork = p.total * (128 / QA);
+
+	for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+		const int t = work >> 3, q0 = (work & 7) * QA, q = q0 + ql;
+		v2f r[8];
+
+		/* load x[q + 128 (i + 64 j)] and window (fft.cl:415-417) */
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int n = q + 128 * (i + TS * j);
+			v2f xv;
+			if (HALF) {
+				typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+				const h2 h = reinterpret_cast<const h2 *>(p.iq)[(size_t)t * p.hop + n];
+				xv = v2f{ (float)h.x, (float)h.y };			/* v_cvt_f32_f16: exact */
+			} else {
+				xv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p.iq + (size_t)t * p.hop + n));
+			}
+			const float wv = p.win[n];
+			r[j] = v2f{ xv.x * wv, xv.y * wv };
+		}
+
+		/* passes p = 1, 8, 64 of the 512-point sub-plan (fft.cl:278-350 with t = 64) */
+		int pp = 1;
+#pragma unroll
+		for (int q8 = 0; q8 < 3; q8++) {
+			const int k = i & (pp - 1);
+			if (q8 > 0) {
+				const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(r[j], tw[j - 1]);
+			}
+			dft8(r, s12);
+			const int j0 = ((i - k) << 3) + k;
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[j0 + jj * pp] = r[R8_PERM(jj)];
+			__syncthreads();
+			if (q8 < 2) {
+#pragma unroll
+				for (int j = 0; j < 8; j++)
+					r[j] = buf[i + TS * j];
+				__syncthreads();
+			}
+			pp <<= 3;
+		}
+
+		/* the 16 blocks of 512 results, contiguous in the intermediate spectrum */
+		{
+			const v2f *all = reinterpret_cast<const v2f *>(smem_raw);
+			v2f *dst = reinterpret_cast<v2f *>(p.scratch) + (size_t)t * N + (size_t)M * q0;
+			for (int idx = threadIdx.x; idx < QA * M; idx += 1024)
+				dst[idx] = all[(idx >> 9) * ROW + (idx & (M - 1))];
+		}
+		__syncthreads();
+	}
+}
+
+template <bool WRITE_FFT>
+__global__ __launch_bounds__(512)
+void k1h_stage_b(const K1Params p)
+{
+	constexpr int N = 65536, KB = 32;
+	__shared__ v2f l4[128 * KB];			/* after pass 4: [(i3, jj4)][k] */
+	__shared__ v2f l5[128 * KB];			/* after pass 5: [(i4, jj5, jj4)][k] */
+	const int kl = threadIdx.x & (KB - 1);
+	const int a  = threadIdx.x >> 5;			/* 0..15 */
+	const int kgroups = 512 / KB;				/* 16 */
+	const int ntiles = p.total / p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	for (int work = blockIdx.x; work < ntiles * kgroups; work += gridDim.x) {
+	const int tile = work / kgroups, k = (work - tile * kgroups) * KB + kl;
+	const int t0 = tile * p.tile;
+	float live[8], vmax[8];
+#pragma unroll
+	for (int q = 0; q < 8; q++) { live[q] = 0.0f; vmax[q] = vmax_init; }
+
+	for (int g0 = 0; g0 < p.tile; g0 += 2) {
+		uint32_t pack[8];
+#pragma unroll
+		for (int q = 0; q < 8; q++) pack[q] = 0;
+
+#pragma unroll 1
+		for (int u = 0; u < 2; u++) {
+			const int t = t0 + g0 + u;
+			const v2f *w = reinterpret_cast<const v2f *>(p.scratch) + (size_t)t * N;
+			v2f r[8];
+
+			/* pass 4, p = 512: item i3 = a combines blocks q = a + 16 j at offset k; twiddle index k */
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = w[512 * (a + 16 * j) + k];
+			{
+				const v2f *tw = twg + p.tw_off[2] + k * 7;
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(r[j], tw[j - 1]);
+			}
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				l4[(a * 8 + jj) * KB + kl] = r[R8_PERM(jj)];
+			__syncthreads();
+
+			/* pass 5, p = 4096: item (i4, jj4) combines i3 = i4 + 2 j; twiddle index k + 512 jj4 */
+			{
+				const int i4 = a >> 3, jj4 = a & 7;
+#pragma unroll
+				for (int j = 0; j < 8; j++)
+					r[j] = l4[((i4 + 2 * j) * 8 + jj4) * KB + kl];
+				const v2f *tw = twg + p.tw_off[3] + (k + 512 * jj4) * 7;
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(r[j], tw[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					l5[(i4 * 64 + jj * 8 + jj4) * KB + kl] = r[R8_PERM(jj)];
+			}
+			__syncthreads();
+
+			/* radix-2 pass, p = 32768 (fft.cl:428-458): butterflies on columns (j, j + 32768),
+			 * j = k + 512 m, m = 4a + c; twiddle index j */
+			v2f x[8];
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int m = 4 * a + c;
+				const int jcol = k + 512 * m;
+				v2f va = l5[m * KB + kl];
+				v2f vb = l5[(64 + m) * KB + kl];
+				vb = c_mul(vb, twg[p.tw_off[4] + jcol]);
+				DFT2(va, vb);
+				x[c] = va;
+				x[c + 4] = vb;
+			}
+			/* (l4 is rewritten only after the next spectrum's first barrier; l5 after its second) */
+
+			if (WRITE_FFT) {
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					const int jcol = k + 512 * (4 * a + c);
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol] = x[c];
+					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol + N / 2] = x[c + 4];
+				}
+			}
+
+			/* epilogue (display.cl:136,161-168), 16-bit bin indices */
+			float l2[8];
+			uint32_t bn[8];
+			uint32_t amb = 0;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				uint32_t ab;
+				const float rr = bin_fast(x[q].x, x[q].y, bk, &l2[q], &ab);
+				amb = amb > ab ? amb : ab;
+				bn[q] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
+			}
+			if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const float v = __builtin_fmaf(bk.A, l2[q], bk.C);
+					const float rr = __builtin_rintf(v);
+					const float am = __builtin_fmaf(__builtin_fabsf(l2[q]), bk.kappa, __builtin_fabsf(v - rr));
+					if (!(am <= bk.amb)) {
+						float nl2;
+						bn[q] = bin_exact(x[q].x, x[q].y, l2[q], (int)bn[q], bk.thr, bk.nb, &nl2);
+						l2[q] = nl2;
+					}
+				}
+			}
+			const bool store_row = (t >= p.wf_first);
+			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * N;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const int col = k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2);
+				pack[q] |= bn[q] << (16 * u);
+				live[q] = __builtin_fmaf(live[q], p.w, l2[q]);
+				vmax[q] = max_f32(vmax[q], l2[q]);
+				if (store_row)
+					wf_row[col] = l2[q] * F_HALF_LOG10_2;
+			}
+		}
+		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 1) * N;
+#pragma unroll
+		for (int q = 0; q < 8; q++)
+			dst[k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2)] = pack[q];
+	}
+	float2 *pp2 = p.partial + (size_t)tile * N;
+#pragma unroll
+	for (int q = 0; q < 8; q++)
+		pp2[k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2)] = make_float2(live[q] * F_HALF_LOG10_2,
+			(vmax[q] == vmax_init) ? -1000.0f : vmax[q] * F_HALF_LOG10_2);
+	__syncthreads();		/* all reads of l5 done before the next work item's first stores */
+	}
+}
+
+static hipError_t launch_k1h(const K1Params &p, hipStream_t s)
+{
+	constexpr size_t lds_a = (size_t)16 * 513 * sizeof(float2);
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+		attr_set = true;
+	}
+	int blocks_a = p.total * 8;
+	if (blocks_a > 512) blocks_a = 512;			/* 2 work-groups of 64 KiB LDS per CU */
+	if (p.iq_half)
+		hipLaunchKernelGGL(k1h_stage_a<true>, dim3(blocks_a), dim3(1024), lds_a, s, p);
+	else
+		hipLaunchKernelGGL(k1h_stage_a<false>, dim3(blocks_a), dim3(1024), lds_a, s, p);
+	if (hipGetLastError() != hipSuccess)
+		return hipErrorLaunchFailure;
+	int blocks_b = (p.total / p.tile) * 16;
+	if (blocks_b > 512) blocks_b = 512;
+	if (p.fft_out)
+		hipLaunchKernelGGL(k1h_stage_b<true>, dim3(blocks_b), dim3(512), 0, s, p);
+	else
+		hipLaunchKernelGGL(k1h_stage_b<false>, dim3(blocks_b), dim3(512), 0, s, p);
+	return hipGetLastError();
+}
+
 hipError_t launch_k1(const K1Params &p, hipStream_t s)
 {
+	if (p.variant == 4)
+		return launch_k1h(p, s);
 	const int tiles = p.total / p.tile;
 	if (p.variant == 3) {
 		if (p.log2n != 13)

@@ -30,16 +30,20 @@ extern "C" {
 /* Geometry and kernel constants.  Zero / negative fields take the reference
  * defaults: fft_len_log 10 (private.h:21), n_bins 128 (display.cl:96),
  * wf_rows 1024 (cl.c:528), t0r 16, t0d 1024, alpha 0.002 (cl.c:714-716). */
+#define FOSPHOR_AMD_IQ_FP32 0	/* interleaved float (re, im), 8 B per sample: the reference's format */
+#define FOSPHOR_AMD_IQ_FP16 1	/* interleaved IEEE half (re, im), 4 B per sample; fft_len_log = 16 only */
+
 struct fosphor_amd_config
 {
-	int   fft_len_log;	/* 10 supported in this round */
-	int   n_bins;		/* 16..256, multiple of 16 */
+	int   fft_len_log;	/* 10 (the reference's), 13, or 16 */
+	int   n_bins;		/* 16..512, multiple of 16 */
 	int   wf_rows;		/* power of two */
 	float t0r, t0d, alpha;
 	int   device;		/* HIP device ordinal; -1 = current */
 	int   max_spectra;	/* capacity of one launch (all batches together); 0 = 1024 */
 	int   max_batches;	/* most batches in one launch; 0 = max(8, max_spectra/1024) */
 	void *stream;		/* hipStream_t to run on; NULL = create a private one */
+	int   iq_format;	/* FOSPHOR_AMD_IQ_*: format of every sample buffer handed to this instance */
 };
 
 /* fosphor_init with explicit geometry.  NULL on failure (message on stderr). */

@@ -574,6 +574,108 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built):
     f.close()
 
 
+def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
+    """N = 65536 in two LDS stages (passes 1-3 per residue mod 128, passes 4-5 + radix 2 per offset mod 512):
+    the bits of the oracle's 8.8.8.8.8.2 plan, fp32 and fp16 input."""
+    torch = torch_cuda
+    n = 65536
+    o = Oracle(fft_len_log=16, n_bins=512, wf_rows=64)
+    x = gaussian_iq(8 * n, 90, sigma=1.0).reshape(8, n, 2)
+    x[3] *= 1e-4
+    x[5, 40000, 1] = np.inf
+    x[6, 123, 0] = np.nan
+    f = amd.Fosphor(fft_len_log=16, n_bins=512, wf_rows=64, max_spectra=16)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    assert f.fft_device(d_in, d_out, 8) == 0
+    want = Oracle.fft(x, o.window, fft_len_log=16)
+    got = d_out.cpu().numpy()
+    assert np.array_equal(canon_bits(got), canon_bits(want)), "%d words differ" % (canon_bits(got) != canon_bits(want)).sum()
+    ref = np.fft.fft((x[0, :, 0].astype(np.float64) + 1j * x[0, :, 1]) * o.window.astype(np.float64))
+    g = got[0, :, 0].astype(np.float64) + 1j * got[0, :, 1]
+    assert np.max(np.abs(g - ref)) / np.max(np.abs(ref)) < 2e-6
+    f.close()
+    # fp16 IQ: widened exactly on load
+    xh = (x[:4] * 0.05).astype(np.float16)
+    fh = amd.Fosphor(fft_len_log=16, n_bins=512, wf_rows=64, max_spectra=16, iq_fp16=True)
+    d_h = torch.from_numpy(xh).cuda()
+    d_o = torch.empty((4, n, 2), dtype=torch.float32, device="cuda")
+    assert fh.fft_device(d_h, d_o, 4) == 0
+    want = Oracle.fft(xh.astype(np.float32), o.window, fft_len_log=16)
+    assert np.array_equal(canon_bits(d_o.cpu().numpy()), canon_bits(want))
+    fh.close()
+
+
+def test_c5_geometry_vs_oracle(amd, torch_cuda, oracle_built):
+    """BASELINE config C5 on one GPU: 65536-point FFT, fp16 IQ, 512 bins; two launches with state
+    carry-over, then the host path.  The oracle gets the same fp16 values widened to fp32."""
+    torch = torch_cuda
+    n, nb, rows = 65536, 512, 64
+    f = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=64, iq_fp16=True)
+    o = Oracle(fft_len_log=16, n_bins=nb, wf_rows=rows)
+    assert f.histo_scale == o.histo_scale and f.histo_offset == o.histo_offset
+    t0 = 0
+    for call, n_spec in enumerate([16, 48]):
+        x = add_tone(gaussian_iq(n_spec * n, 91 + call), 0.05, 0.0313, t0=t0).astype(np.float16)
+        t0 += n_spec * n
+        assert f.process_device(torch.from_numpy(x).cuda(), 1, n_spec) == 0
+        assert o.process(x.astype(np.float32), strict=False, nthreads=8) == 0
+        assert f.waterfall_pos == o.waterfall_pos
+        assert np.array_equal(f.hitcount, o.hitcount.T), "call %d: hit counts" % call
+        assert int(f.hitcount.sum()) == n_spec * n
+        keep = (o.waterfall_pos - min(n_spec, rows) + np.arange(min(n_spec, rows))) & (rows - 1)
+        assert_close(f.waterfall[keep], o.waterfall[keep], "C5 waterfall")
+        assert_close(f.spectrum[0, :, 1], o.spectrum[0, :, 1], "C5 live")
+        assert_close(f.spectrum[1, :, 1], o.spectrum[1, :, 1], "C5 max-hold")
+        assert_hist_close(f.histogram, o.histogram, "C5 histogram")
+    xh = gaussian_iq(16 * n, 93).astype(np.float16)
+    assert f.process(xh) == 0 and o.process(xh.astype(np.float32), strict=False) == 0	# host path, fp16 samples
+    assert np.array_equal(f.hitcount, o.hitcount.T)
+    assert f.process(xh[:8 * n]) == -errno.EINVAL						# not a multiple of 16 spectra
+    f.close()
+    # fp16 IQ with the 1024-point kernels is refused at init, loudly
+    with pytest.raises(RuntimeError):
+        amd.Fosphor(iq_fp16=True)
+
+
+def test_c5_sharded_two_ranks(amd, torch_cuda, oracle_built):
+    """C5 sharded: two ranks take 32 spectra each of one 64-spectrum frame (fp16 IQ); combined partials
+    give the oracle's counts for the whole frame on both ranks."""
+    torch = torch_cuda
+    n, nb, rows, total = 65536, 512, 64, 64
+    x = add_tone(gaussian_iq(total * n, 95), 0.03, 0.2).astype(np.float16)
+    d = torch.from_numpy(x).cuda()
+    ranks = [amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=32, iq_fp16=True) for _ in range(2)]
+    parts = []
+    for r, fr in enumerate(ranks):
+        off = r * (total // 2)
+        assert fr.accumulate_device(d[off * n:(off + total // 2) * n], total // 2, off, total) == 0
+        fr.finish()
+        parts.append(fr.partials())
+    from gr_fosphor_amd.dist import wrap_device_array
+    hc = [wrap_device_array(p.d_hc, (p.n_hc,), torch.int32) for p in parts]
+    ls = [wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32) for p in parts]
+    mx = [wrap_device_array(p.d_max, (p.n_cols,), torch.float32) for p in parts]
+    hc_sum, ls_sum, mx_max = hc[0] + hc[1], ls[0] + ls[1], torch.maximum(mx[0], mx[1])
+    for r in range(2):
+        hc[r].copy_(hc_sum); ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
+    torch.cuda.synchronize()
+    for fr in ranks:
+        assert fr.merge(total) == 0
+    o = Oracle(fft_len_log=16, n_bins=nb, wf_rows=rows)
+    assert o.process(x.astype(np.float32), strict=False, nthreads=8) == 0
+    for fr in ranks:
+        assert np.array_equal(fr.hitcount, o.hitcount.T)
+        assert_hist_close(fr.histogram, o.histogram, "C5 sharded histogram")
+        assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "C5 sharded live")
+        assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "C5 sharded max-hold")
+    # rank 1 owns the last 32 spectra; rank 0's 32 rows were written at ring rows 0..31
+    assert_close(ranks[1].waterfall[32:64], o.waterfall[32:64], "C5 sharded waterfall (rank 1 rows)")
+    assert_close(ranks[0].waterfall[0:32], o.waterfall[0:32], "C5 sharded waterfall (rank 0 rows)")
+    for fr in ranks:
+        fr.close()
+
+
 @pytest.mark.parametrize("n_bins,wf_rows,consts", [
     (16, 1024, None), (64, 256, None), (192, 1024, (4.0, 256.0, 0.01)), (256, 2048, (32.0, 4096.0, 0.0005)),
 ])
