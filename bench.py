@@ -15,10 +15,12 @@ waterfall, 1xMI355X); per-GPU work is the same at every N (weak scaling, configs
          fosphor_process() calls of the reference (cl.c:870-968); steps are submitted
          --batches-per-launch at a time (fosphor_amd_process_device), which changes launch
          granularity, not results.
-  N > 1  ("frame" mode): the spectra of a display frame (--batches-per-launch steps per GPU) are
-         time-sharded over the ranks; hit counts / live sums / max are all-reduced over RCCL once
-         per frame and every rank applies the same state update.  The all-reduce of
-         frame k overlaps the FFT of frame k+1.
+  N > 1  ("frame" mode): the spectra of a display frame (--batches-per-launch steps per GPU, default
+         256 = 1.1 ms of compute; a 60 Hz display frame would be 16 ms) are time-sharded over the
+         ranks; hit counts / live sums / max are all-reduced over RCCL once per frame and every rank
+         applies the same state update.  The all-reduce of frame k overlaps the FFT of
+         frame k+1.  FOSPHOR_AMD_FORCE_EXCHANGE=1 runs the collectives on a single rank (smoke test
+         of the RCCL path: stream ordering, library-owned buffers).
 
 The input ring is larger than the 256 MiB Infinity Cache so IQ reads come from HBM.
 The defaults (32768 steps = 34 G samples, ~80 ms) are long enough to be past the first few
@@ -53,8 +55,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=32768)
     ap.add_argument("--warmup", type=int, default=2048)
     ap.add_argument("--bins", type=int, default=256)
-    ap.add_argument("--batches-per-launch", type=int, default=64)
-    ap.add_argument("--ring-batches", type=int, default=128, help="distinct batches of IQ resident in HBM (8 MiB each)")
+    ap.add_argument("--batches-per-launch", type=int, default=0,
+                    help="steps per launch (batch mode, default 64) / per display frame and GPU (frame mode, default 256)")
+    ap.add_argument("--ring-batches", type=int, default=0, help="distinct batches of IQ resident in HBM (8 MiB each); default 2 launches")
     ap.add_argument("--mode", choices=["auto", "batch", "frame"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -96,16 +99,24 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("FOSPHOR_AMD_FORCE_EXCHANGE"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from _pkg import gr_fosphor_amd
     from gr_fosphor_amd.dist import ShardedFosphor
 
     mode = args.mode if args.mode != "auto" else ("batch" if world == 1 else "frame")
-    F = max(1, args.batches_per_launch)
-    ring = max(F, (args.ring_batches // F) * F)
+    # batch mode: 64 steps per launch (more pushes the intermediates out of the Infinity Cache).
+    # frame mode: a display frame of 256 steps per GPU (1.1 ms of compute; 60 Hz would be 16 ms): the state
+    # update runs once per frame whatever its length, so a longer frame only makes the exchange and the host's
+    # per-frame work (three collectives) rarer.
+    F = args.batches_per_launch if args.batches_per_launch > 0 else (64 if mode == "batch" else 256)
+    ring = args.ring_batches if args.ring_batches > 0 else 2 * F
+    ring = max(F, (ring // F) * F)
 
     # synthetic white complex Gaussian IQ, sigma 0.05 per component, resident in HBM
     g = torch.Generator(device="cuda")
@@ -144,7 +155,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -235,9 +246,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_seconds)
+        # RCCL prints a version banner through C stdio, which would otherwise be flushed after this line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

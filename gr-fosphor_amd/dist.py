@@ -37,9 +37,12 @@ def allreduce_partials(hc, live_sum, vmax, group=None, async_op=False):
     (RCCL on GPU tensors, gloo on CPU tensors in the tests).  hc must be an integer tensor
     (uint32 counts viewed as int32: sums stay below 2^31 for any batch < 2^31 spectra).
     async_op=True returns the work handles (wait() makes the current stream wait, not the host)."""
+    import os
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return []
+    if dist.get_world_size(group) == 1 and not os.environ.get("FOSPHOR_AMD_FORCE_EXCHANGE"):
+        return []		# (the override runs the collectives on a single rank: a smoke test of the RCCL path)
     works = [
         dist.all_reduce(hc, op=dist.ReduceOp.SUM, group=group, async_op=True),
         dist.all_reduce(live_sum, op=dist.ReduceOp.SUM, group=group, async_op=True),
