@@ -116,7 +116,6 @@ struct fosphor
 	int wf_pos;
 	int last_batches;			/* batches in the most recent launch (hitcount view) */
 	int last_slot0;
-	int acc_total;				/* pending accumulate (multi-GPU split) */
 
 	/* the rise/decay table serves batches up to kRiseMax (K3's 16-bit path needs it) */
 	bool rise_ok(int batch) const { return batch <= 8192; }
@@ -1030,7 +1029,6 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	/* the ring advances with the data (host state), so the next frame can be accumulated
 	 * before this one is merged */
 	self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
-	self->acc_total = total_batch;
 	self->state = ST_PENDING;
 	return 0;
 error:

@@ -1335,10 +1335,15 @@ void k_bin_hook(const float2 *__restrict__ fft, uint8_t *__restrict__ bin, float
 		float2 v = fft[i];
 		float l2; uint32_t ab;
 		const float r = bin_fast(v.x, v.y, bk, &l2, &ab);
-		uint32_t b = pack_bin(r, top, 0, 0) & 0xff;
+		/* the two ways the K1 variants turn the guess into an index: saturating byte convert
+		 * (<= 256 bins) or clamp + integer convert (16-bit indices) */
+		uint32_t b = p.bins16 ? (uint32_t)(int)__builtin_amdgcn_fmed3f(r, 0.0f, top) : (pack_bin(r, top, 0, 0) & 0xff);
 		if (ab > __float_as_uint(bk.amb) || force_exact)
 			b = bin_exact(v.x, v.y, l2, (int)__builtin_amdgcn_fmed3f(r, 0.0f, top), bk.thr, bk.nb, &l2);
-		bin[i] = (uint8_t)b;
+		if (p.bins16)
+			reinterpret_cast<uint16_t *>(bin)[i] = (uint16_t)b;
+		else
+			bin[i] = (uint8_t)b;
 		pwr[i] = l2 * F_HALF_LOG10_2;
 	}
 }

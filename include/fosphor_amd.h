@@ -104,7 +104,8 @@ int fosphor_amd_read(struct fosphor *self, int which, void *host, uint64_t bytes
 int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_out, int n_spectra);
 
 /* Kernel-level test hook: per-sample bin index and approximate log-power of FFT
- * outputs already in device memory: d_fft float2[n], d_bin uint8[n], d_pwr float[n]. */
+ * outputs already in device memory: d_fft float2[n], d_pwr float[n], d_bin uint8[n] -- or
+ * uint16[n] on instances with 16-bit bin indices (n_bins > 256 or fft_len_log != 10). */
 int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *d_pwr, int n);
 
 /* ---- multi-GPU split (one process per GPU; exchange done by the caller) --- */
