@@ -269,6 +269,36 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
     f.close(); f2.close()
 
 
+@pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"}])
+def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
+    """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode and the
+    two-waves-per-spectrum K1 are scheduling choices: several back-to-back launches, then a switch to
+    the sharded path and back, must leave exactly the state of the sequential reference calls."""
+    torch = torch_cuda
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nbat, b, launches = 4, 128, 4
+    f = amd.Fosphor(max_spectra=nbat * b)
+    o = Oracle()
+    for L in range(launches):
+        x = add_tone(gaussian_iq(nbat * b * 1024, 300 + L), 0.2, 0.05 * (L + 1))
+        assert f.process_device(torch.from_numpy(x).cuda(), nbat, b) == 0		# not synchronised in between
+        for k in range(nbat):
+            assert o.process(x[k * b * 1024:(k + 1) * b * 1024], nthreads=8) == 0
+    compare_state(f, o, "4 launches of 4 x 128 (%s)" % env)
+    # sharded path right behind the pipelined launches (one rank holding the whole batch), then back
+    x = gaussian_iq(256 * 1024, 310)
+    assert f.accumulate_device(torch.from_numpy(x).cuda(), 256, 0, 256) == 0
+    assert f.merge(256) == 0
+    assert o.process(x, nthreads=8) == 0
+    x = gaussian_iq(2 * 64 * 1024, 311)
+    assert f.process_device(torch.from_numpy(x).cuda(), 2, 64) == 0
+    for k in range(2):
+        assert o.process(x[k * 64 * 1024:(k + 1) * 64 * 1024], nthreads=8) == 0
+    compare_state(f, o, "after switching paths (%s)" % env)
+    f.close()
+
+
 def test_ring_overwrite_within_one_launch(amd, torch_cuda, oracle_built):
     """More spectra than waterfall rows in one launch: the last wf_rows spectra survive, exactly
     as after the equivalent sequence of reference calls."""
