@@ -1372,11 +1372,14 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
 #ifndef K2_INFLIGHT
 #define K2_INFLIGHT 4
 #endif
-__global__ __launch_bounds__(256)
+/* NW waves per work-group: 4 where the kernel has to fit beside K1 (8-bit indices, N = 1024); 16 for the
+ * 16-bit-index geometries, whose grids are small (N/64 x chunks) and whose rows are latency-bound */
+template <int NW>
+__global__ __launch_bounds__(64 * NW)
 void k2_count(const K2Params p)
 {
 	extern __shared__ uint32_t h[];			/* [n_bins][32] packed pairs */
-	__shared__ float red_s[4][64], red_m[4][64];
+	__shared__ float red_s[NW][64], red_m[NW][64];
 
 	const int tid  = threadIdx.x;
 	const int lane = tid & 63;
@@ -1390,7 +1393,7 @@ void k2_count(const K2Params p)
 	const int hcol = lane & 31;
 	const uint32_t inc = (lane & 32) ? 0x10000u : 1u;
 
-	for (int i = tid; i < nb * 32; i += 256)
+	for (int i = tid; i < nb * 32; i += 64 * NW)
 		h[i] = 0;
 	__syncthreads();
 
@@ -1402,11 +1405,11 @@ void k2_count(const K2Params p)
 		const uint32_t nq16 = p.chunk >> 1, n = p.n;
 		uint32_t q = wv;
 #pragma unroll 1
-		for (; q + 4 * (K2_INFLIGHT - 1) < nq16; q += 4 * K2_INFLIGHT) {
+		for (; q + NW * (K2_INFLIGHT - 1) < nq16; q += NW * K2_INFLIGHT) {
 			uint32_t v[K2_INFLIGHT];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++)
-				v[u] = src16[(q + 4 * u) * n + lane];
+				v[u] = src16[(q + NW * u) * n + lane];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++) {
 				atomicAdd(&h[(v[u] & 0xffffu) * 32 + hcol], inc);
@@ -1414,7 +1417,7 @@ void k2_count(const K2Params p)
 			}
 		}
 #pragma unroll 1
-		for (; q < nq16; q += 4) {
+		for (; q < nq16; q += NW) {
 			const uint32_t v = src16[q * n + lane];
 			atomicAdd(&h[(v & 0xffffu) * 32 + hcol], inc);
 			atomicAdd(&h[(v >> 16) * 32 + hcol], inc);
@@ -1424,11 +1427,11 @@ void k2_count(const K2Params p)
 		const uint32_t nq = p.chunk >> 2, n = p.n;
 		uint32_t q = wv;
 #pragma unroll 1
-		for (; q + 4 * (K2_INFLIGHT - 1) < nq; q += 4 * K2_INFLIGHT) {	/* independent loads in flight per thread */
+		for (; q + NW * (K2_INFLIGHT - 1) < nq; q += NW * K2_INFLIGHT) {	/* independent loads in flight per thread */
 			uint32_t v[K2_INFLIGHT];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++)
-				v[u] = src[(q + 4 * u) * n + lane];
+				v[u] = src[(q + NW * u) * n + lane];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++) {
 				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
@@ -1438,7 +1441,7 @@ void k2_count(const K2Params p)
 			}
 		}
 #pragma unroll 1
-		for (; q < nq; q += 4) {
+		for (; q < nq; q += NW) {
 			const uint32_t v = src[q * n + lane];
 			atomicAdd(&h[((v      ) & 0xff) * 32 + hcol], inc);
 			atomicAdd(&h[((v >>  8) & 0xff) * 32 + hcol], inc);
@@ -1454,7 +1457,7 @@ void k2_count(const K2Params p)
 		const float2 *pp = p.partial + (size_t)c * tiles * p.n + x0 + lane;
 		float s = 0.0f, m = -1000.0f;
 #pragma unroll 2
-		for (int j = wv; j < tiles; j += 4) {
+		for (int j = wv; j < tiles; j += NW) {
 			const float2 v = pp[(size_t)j * p.n];
 			const int t_last = p.t_offset + t_in + (j + 1) * p.tile - 1;
 			/* (1-a)^k as exp2(k log2(1-a)): relative error ~1e-6 where the weight is not negligible */
@@ -1469,7 +1472,7 @@ void k2_count(const K2Params p)
 	if (tid < 64) {
 		float s = 0.0f, m = -1000.0f;
 #pragma unroll
-		for (int j = 0; j < 4; j++) {				/* fixed order: deterministic floats */
+		for (int j = 0; j < NW; j++) {				/* fixed order: deterministic floats */
 			s += red_s[j][tid];
 			m = (m < red_m[j][tid]) ? red_m[j][tid] : m;
 		}
@@ -1482,7 +1485,7 @@ void k2_count(const K2Params p)
 		 * (32 KiB at 256 bins); K3 unpacks */
 		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)c * (p.n / 64) + blockIdx.x) * nb * 32;
 #pragma unroll 2
-		for (int i = tid; i < nb * 32; i += 256)
+		for (int i = tid; i < nb * 32; i += 64 * NW)
 			d[i] = h[i];
 		return;
 	}
@@ -1491,11 +1494,11 @@ void k2_count(const K2Params p)
 	const int sh = (lane & 32) ? 16 : 0;
 	if (cpb == 1) {
 #pragma unroll 1
-		for (int b = wv; b < nb; b += 4)
+		for (int b = wv; b < nb; b += NW)
 			dst[(size_t)b * p.n] = (h[b * 32 + hcol] >> sh) & 0xffffu;
 	} else {
 #pragma unroll 1
-		for (int b = wv; b < nb; b += 4) {
+		for (int b = wv; b < nb; b += NW) {
 			const uint32_t v = (h[b * 32 + hcol] >> sh) & 0xffffu;
 			if (v)
 				atomicAdd(&dst[(size_t)b * p.n], v);
@@ -1505,7 +1508,11 @@ void k2_count(const K2Params p)
 
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
-	hipLaunchKernelGGL(k2_count, dim3((p.n / 64), n_chunks), dim3(256), (size_t)p.n_bins * 32 * sizeof(uint32_t), s, p);
+	const size_t lds = (size_t)p.n_bins * 32 * sizeof(uint32_t);
+	if (p.bins16)
+		hipLaunchKernelGGL(k2_count<16>, dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
+	else
+		hipLaunchKernelGGL(k2_count<4>, dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	return hipGetLastError();
 }
 
