@@ -1622,18 +1622,23 @@ __global__ __launch_bounds__(256)
 void k3_merge(const K3Params p)
 {
 	const int cells = p.n_bins * p.n;
-	const int gid = blockIdx.x * 256 + threadIdx.x;
 	const float fbatch = (float)p.batch;
 
+	/* the (d, e) table of the 16-bit path sits in LDS: loaded once per work-group, which then strides
+	 * over the cells (the grid is capped, so a 128 MiB state does not reload it 131 072 times) */
+	__shared__ float2 rise_lds[MODE == 0 ? 1025 : 1];
+	if (MODE == 0) {
+		for (int i = threadIdx.x; i <= p.batch && i < 1025; i += 256)
+			rise_lds[i] = p.rise[i];
+		__syncthreads();
+	}
+
+	for (int gid = blockIdx.x * 256 + threadIdx.x; gid < cells + p.n; gid += gridDim.x * 256) {
 	if (MODE == 0) {
 		/* 16-bit slab-major counts as K2 leaves them ([slab of 64 columns][bin][32] dwords, columns
 		 * c and c + 32 in the low / high half): thread gid reads the gid-th 16-bit word of a batch
 		 * (2 B per batch, 8 batches in flight); the (d, e) table sits in LDS (one dependent lookup
 		 * per batch per cell). */
-		__shared__ float2 rise_lds[1025];
-		for (int i = threadIdx.x; i <= p.batch && i < 1025; i += 256)
-			rise_lds[i] = p.rise[i];
-		__syncthreads();
 		if (gid < cells) {
 			const int nb = p.n_bins;
 			const int slab = gid / (nb * 64);
@@ -1751,18 +1756,20 @@ void k3_merge(const K3Params p)
 		p.spectrum[i]      = make_float2(vx, live);
 		p.spectrum[p.n + i] = make_float2(vx, mh);
 	}
+	}	/* cell loop */
 }
 
 hipError_t launch_k3(const K3Params &p, hipStream_t s)
 {
 	const int threads = p.n_bins * p.n + p.n;
-	const dim3 grid((threads + 255) / 256);
+	int blocks = (threads + 255) / 256;
+	if (blocks > 8192) blocks = 8192;
 	if (p.hc16)
-		hipLaunchKernelGGL(k3_merge<0>, grid, dim3(256), 0, s, p);
+		hipLaunchKernelGGL(k3_merge<0>, dim3(blocks), dim3(256), 0, s, p);
 	else if (p.rise)
-		hipLaunchKernelGGL(k3_merge<1>, grid, dim3(256), 0, s, p);
+		hipLaunchKernelGGL(k3_merge<1>, dim3(blocks), dim3(256), 0, s, p);
 	else
-		hipLaunchKernelGGL(k3_merge<2>, grid, dim3(256), 0, s, p);
+		hipLaunchKernelGGL(k3_merge<2>, dim3(blocks), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 
