@@ -168,8 +168,15 @@ def main(argv):
                               rel_step=fx.rel_step if fx.mode == 1 else None, labels=labels))
         json.dump(cases, open(os.path.join(OUT, "axis_labels.json"), "w"), indent=1)
 
+    if not argv or "geom" in argv:
+        # render geometry / pixel <-> unit mapping straight from the reference's fosphor.c (oracle/_ref/geom_dump)
+        import subprocess
+        out = subprocess.check_output([os.path.join(HERE, "_ref", "geom_dump")]).decode()
+        cases = json.loads(out)
+        json.dump(cases, open(os.path.join(OUT, "render_geometry.json"), "w"), indent=1)
+
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main([a for a in sys.argv[1:] if a in gc.CASES or a in ("fft512", "cmap", "axis")])
+    main([a for a in sys.argv[1:] if a in gc.CASES or a in ("fft512", "cmap", "axis", "geom")])
