@@ -23,9 +23,9 @@ waterfall, 1xMI355X); per-GPU work is the same at every N (weak scaling, configs
          of the RCCL path: stream ordering, library-owned buffers).
 
 The input ring is larger than the 256 MiB Infinity Cache so IQ reads come from HBM.
-The defaults (32768 steps = 34 G samples, ~80 ms) are long enough to be past the first few
-milliseconds of a run, during which the clocks are still settling and K1 -- which is VALU- and
-power-bound -- runs 10-30 % slower (measured: 1280 steps 390 GS/s, 25600 steps 436, 102400 steps 454).
+The defaults (131072 steps = 137 G samples, ~0.3 s) are long enough to be past the first
+milliseconds of a run, during which the clocks are still settling and K1 runs 10-30 % slower
+(measured: 1280 steps 390 GS/s, 32768 steps 450-459, 131072 steps 462-464, 524288 steps 457-461).
 
 roofline: the dominant kernel is K1 (fft_bin).  achieved = 8 B x samples per launch / mean K1
 duration, measured with hipEvents on the library's stream inside the timed region.
@@ -52,8 +52,8 @@ BYTES_PER_SAMPLE = 8		# algorithmic read, one complex fp32 sample
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32768)
-    ap.add_argument("--warmup", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=131072)
+    ap.add_argument("--warmup", type=int, default=4096)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--batches-per-launch", type=int, default=0,
                     help="steps per launch (batch mode, default 64) / per display frame and GPU (frame mode, default 256)")
