@@ -43,8 +43,11 @@ def c3():
     return f, d
 
 
+C5_B = int(os.environ.get("C5_SPECTRA", "128"))	# per-GPU share of a frame; 128 = 1024 spectra over 8 GPUs
+
+
 def c5():
-    n, b = 65536, 128
+    n, b = 65536, C5_B
     f = gr_fosphor_amd.Fosphor(fft_len_log=16, n_bins=512, max_spectra=b, max_batches=8, iq_fp16=True)
     d = torch.empty((b * n, 2), dtype=torch.float32, device="cuda").normal_(0.0, 0.05).to(torch.float16)
     return f, d
@@ -52,4 +55,4 @@ def c5():
 
 if __name__ == "__main__":
     run("C3", c3, lambda f, d: f.process_device_overlap(d, 1, 4096, 2), 4096 * 8192)
-    run("C5", c5, lambda f, d: f.process_device(d, 1, 128), 128 * 65536)
+    run("C5", c5, lambda f, d: f.process_device(d, 1, C5_B), C5_B * 65536)
