@@ -2,7 +2,7 @@
 """One-off large-sample parity check (not part of the test suite: ~10^9 samples): hit counts of every batch
 against the oracle, bit for bit, for several seeds / signal mixes / power ranges, at 128 and 256 bins.
 
-    python3 tools/soak_parity.py [n_seeds]
+    python3 tests/soak_parity.py [n_seeds]          (kept under tests/: it uses the oracle as the checker)
 """
 import os
 import sys
