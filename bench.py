@@ -159,6 +159,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    f.finish()				# instance boot (table uploads, initial fills: cl.c:981-995) is not a step
     pos = run_steps(args.warmup, 0)
     sync()
     # timed region: hipEvents around K1 only (events around K2/K3 too cost ~6 % of throughput:
