@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--ring-batches", type=int, default=0, help="distinct batches of IQ resident in HBM (8 MiB each); default 2 launches")
     ap.add_argument("--mode", choices=["auto", "batch", "frame"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic-twin", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -195,6 +196,15 @@ def main():
             iso = ms_i[0] / n_i[0]
     f.profile(False)
 
+    # the practical ceiling for K1 on this chip: its memory traffic (same loads, order, prefetch depth, stores)
+    # without its arithmetic, measured live on the same buffers
+    twin_ms = None
+    if mode == "batch" and not args.no_traffic_twin:
+        try:
+            twin_ms = f.traffic_twin(iq[:F * samples_per_batch], F, BATCH, reps=50)
+        except Exception:
+            twin_ms = None
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,7 +253,12 @@ def main():
                          "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
                          "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch,
-                         "isolated": isolated},
+                         "isolated": isolated,
+                         "traffic_twin": None if not twin_ms else {
+                             "ms_per_launch": twin_ms,
+                             "k1_isolated_over_twin": (iso / twin_ms) if iso else None,
+                             "note": "a kernel with K1's loads (same tile order, prefetch depth) and stores but no arithmetic, "
+                                     "same buffers: the practical floor the memory system sets for one K1 launch"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_seconds)

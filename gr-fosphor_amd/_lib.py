@@ -93,6 +93,7 @@ SIGNATURES = {
     "fosphor_amd_host_twiddle_count": (C.c_int, []),
     "fosphor_amd_host_twiddles": (C.c_int, [C.c_void_p]),
     "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "fosphor_amd_traffic_twin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
@@ -132,6 +133,7 @@ SIGNATURES = {
                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fosphor_amd_process_device_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "fosphor_amd_traffic_twin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -175,6 +175,14 @@ class Fosphor:
         """False/0: off; True/1: hipEvents around every kernel; 2: around K1 only."""
         self.L.fosphor_amd_profile(self.h, 2 if enable == 2 and enable is not True else (1 if enable else 0))
 
+    def traffic_twin(self, d_samples, n_batches, batch, reps=20):
+        """ms per launch of K1's memory traffic alone (include/fosphor_amd.h)"""
+        ms = C.c_float()
+        rv = self.L.fosphor_amd_traffic_twin(self.h, _ptr(d_samples), int(n_batches), int(batch), int(reps), C.byref(ms))
+        if rv:
+            raise RuntimeError("fosphor_amd_traffic_twin -> %d" % rv)
+        return ms.value
+
     def set_overlap(self, enable):
         return self.L.fosphor_amd_set_overlap(self.h, 1 if enable else 0)
 

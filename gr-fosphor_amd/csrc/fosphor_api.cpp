@@ -1099,6 +1099,39 @@ extern "C" int fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int l
 	return 0;
 }
 
+/* Measurement hook: the memory traffic of one K1 launch (same loads, same stores, same order)
+ * without its arithmetic, on this instance's buffers; average of `reps` launches in ms.  The
+ * intermediates of the current set are overwritten (call between launches, results unaffected:
+ * every launch rewrites them before reading). */
+extern "C" int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samples, int n_batches, int batch,
+                                        int reps, float *ms_out)
+{
+	K1Params k1;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	const int total = n_batches * batch;
+	float ms = 0.0f;
+	if (!self || !d_samples || !ms_out || reps < 1 || total < 16 || total > self->max_spectra || self->log2n != 10 || self->bins16)
+		return -EINVAL;
+	if (fosphor_amd_finish(self) < 0 || prepare(self))
+		return -EIO;
+	fill_k1(self, &k1, d_samples, total, pick_tile(total), 0, total);
+	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+		return -EIO;
+	for (int i = 0; i < 3; i++)
+		(void)launch_k1_traffic_twin(k1, self->stream);
+	(void)hipEventRecord(e0, self->stream);
+	for (int i = 0; i < reps; i++)
+		(void)launch_k1_traffic_twin(k1, self->stream);
+	(void)hipEventRecord(e1, self->stream);
+	if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+		return -EIO;
+	}
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	*ms_out = ms / (float)reps;
+	return 0;
+}
+
 extern "C" void *fosphor_amd_stream(struct fosphor *self)
 {
 	return self ? (void *)self->stream : NULL;

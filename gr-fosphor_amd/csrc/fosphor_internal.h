@@ -109,6 +109,7 @@ struct K3Params {
 };
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
+hipError_t launch_k1_traffic_twin(const K1Params &p, hipStream_t s);
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s);
 hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s);

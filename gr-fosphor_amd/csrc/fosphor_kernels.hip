@@ -619,6 +619,66 @@ void k1_fft_bin(const K1Params p)
 }
 
 /* ------------------------------------------------------------------------ */
+/* K1's memory traffic without K1's arithmetic (measurement hook)             */
+/* ------------------------------------------------------------------------ */
+/* The same persistent grid, tile order, 16-byte non-temporal loads one spectrum ahead, and the same
+ * stores (bin dwords every 4 spectra, tile partials every tile) as k1_fft_bin -- and nothing else.
+ * Its duration is the practical floor the memory system sets for K1 on this chip: bench.py reports
+ * K1's duration next to it (roofline.traffic_twin). */
+__global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
+void k1_traffic_twin(const K1Params p)
+{
+	const int lane   = threadIdx.x & 63;
+	const int wv     = threadIdx.x >> 6;
+	const int ntiles = p.total / p.tile;
+	const int stride = gridDim.x * 4;
+	int tile = blockIdx.x * 4 + wv;
+	if (tile >= ntiles)
+		return;
+	v2f xn[16];
+	load_iq16(xn, p.iq + (size_t)tile * p.tile * p.hop + K1_LANE_SRC(lane));
+	for (; tile < ntiles; tile += stride) {
+		const int t0 = tile * p.tile;
+		v2f acc = { 0.0f, 0.0f };
+		for (int g0 = 0; g0 < p.tile; g0 += 4) {
+#pragma unroll 1
+			for (int u = 0; u < 4; u++) {
+				const int t = t0 + g0 + u;
+				v2f x[16];
+#pragma unroll
+				for (int m = 0; m < 16; m++)
+					x[m] = xn[m];
+				const bool last = (g0 + u + 1 == p.tile);
+				const int t_next = last ? (tile + stride) * p.tile : t + 1;
+				if (!last || tile + stride < ntiles)
+					load_iq16(xn, p.iq + (size_t)t_next * p.hop + K1_LANE_SRC(lane));
+#pragma unroll
+				for (int m = 0; m < 16; m++)
+					acc += x[m];			/* consume the data: 16 adds per spectrum */
+			}
+			uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				dst[64 * m] = __float_as_uint(acc.x) + (uint32_t)m;
+		}
+		float2 *pp = p.partial + (size_t)tile * kN + lane;
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			pp[64 * m] = make_float2(acc.x, acc.y + (float)m);
+	}
+}
+
+hipError_t launch_k1_traffic_twin(const K1Params &p, hipStream_t s)
+{
+	const int tiles = p.total / p.tile;
+	int blocks = (tiles + 3) / 4;
+	if (blocks > kK1MaxBlocks)
+		blocks = kK1MaxBlocks;
+	hipLaunchKernelGGL(k1_traffic_twin, dim3(blocks), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
 /* K1 v2: two waves per spectrum                                             */
 /* ------------------------------------------------------------------------ */
 /* Same arithmetic, same LDS layout, same outputs as k1_fft_bin, but a spectrum is shared by

@@ -147,6 +147,13 @@ int fosphor_amd_merge(struct fosphor *self, int total_batch);
 void fosphor_amd_profile(struct fosphor *self, int enable);
 int  fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3]);
 
+/* The memory traffic of one K1 launch over (d_samples, n_batches, batch) -- its loads in its order
+ * with its prefetch depth, its stores -- without the arithmetic: the practical floor the memory
+ * system sets for that launch.  Average of `reps` launches, in milliseconds.  N = 1024, <= 256 bins.
+ * State and results of the instance are not changed.  0, -EINVAL, -EIO. */
+int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samples, int n_batches, int batch,
+                             int reps, float *ms_out);
+
 /* ---- host-side tables (no GPU needed; exported for tests and for front ends) ---- */
 
 /* The exact bin thresholds the kernels compare |X|^2 against: out[n_bins + 1] doubles.

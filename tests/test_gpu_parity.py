@@ -299,6 +299,29 @@ def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, m
     f.close()
 
 
+def test_traffic_twin_hook_leaves_results_alone(amd, torch_cuda, oracle_built):
+    """fosphor_amd_traffic_twin (K1's loads and stores without its arithmetic, for the bench's practical
+    ceiling) scribbles on the intermediate buffers only: the state sequence is unaffected."""
+    torch = torch_cuda
+    nbat, b = 4, 64
+    f = amd.Fosphor(max_spectra=nbat * b)
+    o = Oracle()
+    for L in range(2):
+        x = gaussian_iq(nbat * b * 1024, 400 + L)
+        d = torch.from_numpy(x).cuda()
+        assert f.process_device(d, nbat, b) == 0
+        ms = f.traffic_twin(d, nbat, b, reps=3)
+        assert 0.0 < ms < 50.0
+        for k in range(nbat):
+            assert o.process(x[k * b * 1024:(k + 1) * b * 1024], nthreads=8) == 0
+    compare_state(f, o, "launch, twin, launch, twin")
+    import ctypes as C
+    bad = C.c_float()
+    assert f.L.fosphor_amd_traffic_twin(f.h, None, nbat, b, 3, C.byref(bad)) == -errno.EINVAL
+    assert f.L.fosphor_amd_traffic_twin(f.h, d.data_ptr(), nbat + 1, b, 3, C.byref(bad)) == -errno.EINVAL	# over capacity
+    f.close()
+
+
 def test_ring_overwrite_within_one_launch(amd, torch_cuda, oracle_built):
     """More spectra than waterfall rows in one launch: the last wf_rows spectra survive, exactly
     as after the equivalent sequence of reference calls."""
