@@ -2,7 +2,7 @@
 """One-off large-sample parity check (not part of the test suite: ~10^9 samples): hit counts of every batch
 against the oracle, bit for bit, for several seeds / signal mixes / power ranges, at 128 and 256 bins.
 
-    python3 tests/soak_parity.py [n_seeds]          (kept under tests/: it uses the oracle as the checker)
+    python3 tests/soak_parity.py [n_seeds [c2|c3|c5]]          (kept under tests/: it uses the oracle as the checker)
 """
 import os
 import sys
@@ -16,6 +16,39 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 from _pkg import gr_fosphor_amd  # noqa: E402
 from oracle_lib import Oracle, add_tone, build_oracle  # noqa: E402
+
+
+def big(n_seeds, log2n, fp16):
+    """the 16-bit-index geometries: N = 8192 (C3) or 65536 (C5, fp16 IQ), 512 bins, device-resident input"""
+    build_oracle(ref=False)
+    threads = min(os.cpu_count() or 1, 64)
+    n = 1 << log2n
+    spectra = (1 << 22) // n * 4		# 16 Mi samples per call
+    total = mismatched = 0
+    t0 = time.time()
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(5000 + seed)
+        sigma = [0.05, 2e-3, 1.5, 0.3][seed % 4]
+        power = [(0, 10), (-20, 5), (10, 2), (-40, 20)][(seed // 4) % 4]
+        f = gr_fosphor_amd.Fosphor(fft_len_log=log2n, n_bins=512, wf_rows=64, max_spectra=spectra, iq_fp16=fp16)
+        o = Oracle(fft_len_log=log2n, n_bins=512, wf_rows=64)
+        f.set_power_range(*power); o.set_power_range(*power)
+        for call in range(2):
+            x = (rng.standard_normal((spectra * n, 2)) * sigma).astype(np.float32)
+            if call:
+                x = add_tone(x, sigma * 3, 0.0377)
+            if fp16:
+                x = x.astype(np.float16)
+            assert f.process_device(torch.from_numpy(x).cuda(), 1, spectra) == 0
+            assert o.process(x.astype(np.float32), strict=False, nthreads=threads) == 0
+            bad = int((f.hitcount != o.hitcount.T).sum())
+            mismatched += bad
+            total += spectra * n
+            if bad:
+                print("seed %d call %d: %d cells differ" % (seed, call, bad))
+        f.close()
+    print("N=%d%s: %d samples, %d mismatching hit-count cells, %.0f s" % (n, " fp16" if fp16 else "", total, mismatched, time.time() - t0))
+    return 1 if mismatched else 0
 
 
 def main(n_seeds):
@@ -50,4 +83,6 @@ def main(n_seeds):
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 8))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    which = sys.argv[2] if len(sys.argv) > 2 else "c2"
+    sys.exit(main(n) if which == "c2" else big(n, 13, False) if which == "c3" else big(n, 16, True))
