@@ -1118,7 +1118,12 @@ void k1h_stage_a(const K1Params p)
 	v2f *buf = reinterpret_cast<v2f *>(smem_raw) + (threadIdx.x & (QA - 1)) * ROW;	/* this residue's row */
 	const int ql = threadIdx.x & (QA - 1);
 	const int i  = threadIdx.x >> 4;				/* sub-FFT work-item, 0..63 */
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	/* twiddles of passes 2 and 3 (p = 8, 64: the first 504 table entries) behind the rows, in LDS */
+	v2f *tws = reinterpret_cast<v2f *>(smem_raw) + QA * ROW;
+	for (int k = threadIdx.x; k < (8 + 64) * 7; k += 1024)
+		tws[k] = reinterpret_cast<const v2f *>(p.tw)[k];
+	__syncthreads();
+	const v2f *twg = tws;
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
 	const int nwork = p.total * (128 / QA);
 
@@ -1324,7 +1329,7 @@ void k1h_stage_b(const K1Params p)
 
 static hipError_t launch_k1h(const K1Params &p, hipStream_t s)
 {
-	constexpr size_t lds_a = (size_t)16 * 513 * sizeof(float2);
+	constexpr size_t lds_a = ((size_t)16 * 513 + (8 + 64) * 7) * sizeof(float2);
 	static bool attr_set = false;
 	if (!attr_set) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
