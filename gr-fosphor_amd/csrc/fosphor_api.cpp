@@ -603,7 +603,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	/* One batch of several chunks (the time shard of a display frame): K2 leaves per-chunk packed
 	 * 16-bit slabs in the upper half of d_hc (no zeroing, no global atomics) and k2c_sum adds them
 	 * into the 32-bit slot.  Needs whole 1024-spectrum chunks and room for cpb slabs. */
-	const int sum16 = !use16 && n_batches == 1 && chunk == 1024 && cpb > 1 && cpb <= self->max_batches &&
+	const int sum16 = (!use16 || batch > 1024) && n_batches == 1 && chunk == 1024 && cpb > 1 && cpb <= self->max_batches &&
 	                  self->max_batches >= 4 && !getenv("FOSPHOR_AMD_NO_SUM16");
 
 	memset(&k2, 0, sizeof(k2));
