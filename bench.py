@@ -5,30 +5,34 @@ Contract (one JSON line on rank 0):
     python bench.py --gpus N --steps K --warmup W
     N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A STEP is one batch of 1024 spectra x 1024 points (1 Mi complex samples, 8 MiB of fp32 IQ) per
-GPU, already resident in HBM, taken through the whole path: windowed FFT -> log-power -> exact
-histogram bin -> hit counts -> persistence-histogram rise/decay, live EMA, max-hold, waterfall.
-Workload = BASELINE.json configs[1] ("C2": 1024-pt FFT, batch=1024, 1024x256 histogram +
-waterfall, 1xMI355X); per-GPU work is the same at every N (weak scaling, configs[3] "C4").
+A STEP is ONE CALL of the library's device-resident entry point with --batches-per-step (256)
+reference batches of BASELINE config C2 -- 1024 spectra x 1024 points each, 1024x256 histogram +
+waterfall -- i.e. 268 435 456 complex samples = 2 GiB of fp32 IQ already resident in HBM, taken
+through the whole path: windowed FFT -> log-power -> exact histogram bin -> hit counts ->
+persistence-histogram rise/decay, live EMA, max-hold, waterfall.  The library cuts a call into
+sub-launches of 64 batches (K1 | K2 | K3 pipelined over streams); EVERY batch gets its own state
+update in order, exactly as 256 successive fosphor_process() calls of the reference would give
+(cl.c:870-968; tests/test_gpu_parity.py::test_multi_batch_launch_equals_sequential_calls).
+--steps / --warmup count such calls.  Before the warm-up an UNTIMED pre-conditioning phase
+(--precondition seconds, default 0.5 s, reported) runs the same steps so that the clocks have
+settled: the first milliseconds of a run are 10-30 % slower.
 
-  N = 1  ("batch" mode): every step gets its own state update, exactly like successive
-         fosphor_process() calls of the reference (cl.c:870-968); steps are submitted
-         --batches-per-launch at a time (fosphor_amd_process_device), which changes launch
-         granularity, not results.
-  N > 1  ("frame" mode): the spectra of a display frame (--batches-per-launch steps per GPU, default
-         256 = 1.1 ms of compute; a 60 Hz display frame would be 16 ms) are time-sharded over the
-         ranks; hit counts / live sums / max are all-reduced over RCCL once per frame and every rank
-         applies the same state update.  The all-reduce of frame k overlaps the FFT of
-         frame k+1.  FOSPHOR_AMD_FORCE_EXCHANGE=1 runs the collectives on a single rank (smoke test
-         of the RCCL path: stream ordering, library-owned buffers).
+  N = 1  ("batch" mode): as above.
+  N > 1  ("frame" mode): the spectra of a display frame (256 steps-worth of batches per GPU) are
+         time-sharded over the ranks; hit counts / live sums / max are all-reduced over RCCL once per
+         frame and every rank applies the same state update; per-GPU work is the same at
+         every N (weak scaling, BASELINE configs[3] "C4").  FOSPHOR_AMD_FORCE_EXCHANGE=1 runs the
+         collectives on a single rank.
 
-The input ring is larger than the 256 MiB Infinity Cache so IQ reads come from HBM.
-The defaults (131072 steps = 137 G samples, ~0.3 s) are long enough to be past the first
-milliseconds of a run, during which the clocks are still settling and K1 runs 10-30 % slower
-(measured: 1280 steps 390 GS/s, 32768 steps 450-459, 131072 steps 462-464, 524288 steps 457-461).
+Other BASELINE configurations: --config C3 (8192-pt FFT, 50 % overlap fused into the read, batch
+4096, 512 bins) and --config C5 (65536-pt FFT, fp16 IQ, 512 bins, the per-GPU share of a sharded
+frame) emit the same JSON shape with their own workload string and roofline convention.
 
-roofline: the dominant kernel is K1 (fft_bin).  achieved = 8 B x samples per launch / mean K1
-duration, measured with hipEvents on the library's stream inside the timed region.
+roofline: the dominant kernel is K1 (fft_bin), bound by the HBM read of the IQ stream (8 B per
+sample, 4 B for fp16 IQ).  K1s of consecutive sub-launches run on alternating streams and overlap
+at their edges, so `achieved` = algorithmic bytes of all K1 launches / time during which at least
+one K1 was running (union of the hipEvent intervals recorded on the streams the kernels run on);
+the plain per-launch average (which counts shared time twice) is reported beside it.
 cpu_baseline: the oracle (oracle/fosphor_oracle.c, the CPU restatement of the reference's
 fft.cl + display.cl) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -43,37 +47,53 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-N_FFT = 1024
-BATCH = 1024
 HBM_PEAK_GBS = 8000.0		# MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-BYTES_PER_SAMPLE = 8		# algorithmic read, one complex fp32 sample
+
+# name -> geometry.  spb = spectra per batch, bps = default batches per step, over = overlap_cc ratio
+CONFIGS = {
+    "C2": dict(log2n=10, bins=256, spb=1024, bps=256, over=1, fp16=False,
+               text="C2: 1024-pt FFT, batch=1024 spectra, 1024x%(bins)d histogram + waterfall; one step = one "
+                    "fosphor_amd_process_device call of %(bps)d such batches (%(msamp)d Mi samples, %(mib)d MiB of IQ), "
+                    "sub-launched %(sub)d batches at a time, every batch with its own state update"),
+    "C3": dict(log2n=13, bins=512, spb=4096, bps=4, over=2, fp16=False,
+               text="C3: 8192-pt FFT, 50 %% overlap (overlap_cc(8192, 2) fused into the read), batch=4096 spectra, "
+                    "8192x%(bins)d histogram + waterfall; one step = one fosphor_amd_process_device_overlap call of "
+                    "%(bps)d such batches (%(msamp)d Mi FFT'd samples)"),
+    "C5": dict(log2n=16, bins=512, spb=128, bps=8, over=1, fp16=True,
+               text="C5: 65536-pt FFT, fp16 IQ, 65536x%(bins)d histogram + waterfall, per-GPU share of a sharded frame = "
+                    "batch of 128 spectra; one step = one fosphor_amd_process_device call of %(bps)d such batches "
+                    "(%(msamp)d Mi samples)"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=131072)
-    ap.add_argument("--warmup", type=int, default=4096)
-    ap.add_argument("--bins", type=int, default=256)
-    ap.add_argument("--batches-per-launch", type=int, default=0,
-                    help="steps per launch (batch mode, default 64) / per display frame and GPU (frame mode, default 256)")
-    ap.add_argument("--ring-batches", type=int, default=0, help="distinct batches of IQ resident in HBM (8 MiB each); default 2 launches")
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2")
+    ap.add_argument("--bins", type=int, default=0)
+    ap.add_argument("--batches-per-step", type=int, default=0, help="reference batches per step (one library call)")
+    ap.add_argument("--ring-steps", type=int, default=2, help="distinct steps of IQ resident in HBM")
+    ap.add_argument("--precondition", type=float, default=0.5, help="seconds of untimed steps before the warm-up")
     ap.add_argument("--mode", choices=["auto", "batch", "frame"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic-twin", action="store_true")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the informational K2/K3 and isolated-K1 passes")
+    ap.add_argument("--strict-ordering", action="store_true", help="keep stream ordering between calls (default: relaxed, "
+                    "the input ring is never rewritten)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def cpu_baseline(bins, seconds):
     """Oracle (CPU restatement of the reference kernels) on all host cores, bounded sample."""
-    import numpy as np
     from oracle_lib import Oracle, build_oracle, gaussian_iq
     build_oracle(ref=False)
     cores = os.cpu_count() or 1
     nthreads = min(cores, 64)			# the display stage has 64 column groups (cl.c:945-950)
     o = Oracle(n_bins=bins)
-    x = gaussian_iq(BATCH * N_FFT, 7)
+    x = gaussian_iq(1024 * 1024, 7)
     o.process(x, nthreads=nthreads)		# warm-up, page in
     n = 0
     t0 = time.perf_counter()
@@ -83,9 +103,11 @@ def cpu_baseline(bins, seconds):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 4096:
             break
-    return {"value": n * BATCH * N_FFT / el / 1e6, "unit": "MSamples/s", "cores": nthreads, "kind": "port",
-            "sample": "%d batches of %d x %d-pt spectra (%.1f s), oracle C restatement of fft.cl+display.cl, "
-                      "%d threads of %d host cores" % (n, BATCH, N_FFT, el, nthreads, cores)}
+    return {"value": n * 1024 * 1024 / el / 1e6, "unit": "MSamples/s", "cores": nthreads, "kind": "port",
+            "sample": "%d batches of 1024 x 1024-pt spectra (%.1f s), oracle C restatement of fft.cl+display.cl, "
+                      "%d threads of %d host cores; the reference's own OpenCL path could not be run: no OpenCL CPU "
+                      "runtime (POCL) exists in this image and reference sources do not travel to the GPU box"
+                      % (n, el, nthreads, cores)}
 
 
 def main():
@@ -110,98 +132,120 @@ def main():
     from _pkg import gr_fosphor_amd
     from gr_fosphor_amd.dist import ShardedFosphor
 
+    cfg = CONFIGS[args.config]
+    n_fft = 1 << cfg["log2n"]
+    bins = args.bins or cfg["bins"]
+    spb = cfg["spb"]
+    over = cfg["over"]
+    bytes_per_sample = 4 if cfg["fp16"] else 8	# algorithmic read per FFT'd sample (materialised-stream convention)
     mode = args.mode if args.mode != "auto" else ("batch" if world == 1 else "frame")
-    # batch mode: 64 steps per launch (more pushes the intermediates out of the Infinity Cache).
-    # frame mode: a display frame of 256 steps per GPU (1.1 ms of compute; 60 Hz would be 16 ms): the state
-    # update runs once per frame whatever its length, so a longer frame only makes the exchange and the host's
-    # per-frame work (three collectives) rarer.
-    F = args.batches_per_launch if args.batches_per_launch > 0 else (64 if mode == "batch" else 256)
-    ring = args.ring_batches if args.ring_batches > 0 else 2 * F
-    ring = max(F, (ring // F) * F)
+    F = args.batches_per_step if args.batches_per_step > 0 else cfg["bps"]
+    ring = max(1, args.ring_steps)
+    samples_per_batch = spb * n_fft			# FFT'd samples
+    hop = n_fft // over
+    # unexpanded stream of one step: (F*spb - 1) * hop + n_fft samples (overlap_cc_impl.cc:64-79)
+    step_stream = (F * spb - 1) * hop + n_fft if over > 1 else F * samples_per_batch
 
-    # synthetic white complex Gaussian IQ, sigma 0.05 per component, resident in HBM
+    # synthetic white complex Gaussian IQ, sigma 0.05 per component, resident in HBM;
+    # the ring is larger than the 256 MiB Infinity Cache, so IQ reads come from HBM
     g = torch.Generator(device="cuda")
     g.manual_seed(7 + rank)
-    iq = torch.empty((ring * BATCH * N_FFT, 2), dtype=torch.float32, device="cuda")
+    iq = torch.empty((ring * step_stream, 2), dtype=torch.float32, device="cuda")
     iq.normal_(0.0, 0.05, generator=g)
-    samples_per_batch = BATCH * N_FFT
+    if cfg["fp16"]:
+        iq = iq.to(torch.float16)
+    torch.cuda.synchronize()
 
     stream = torch.cuda.current_stream().cuda_stream
+    kw = dict(n_bins=bins, max_spectra=F * spb, max_batches=F, fft_len_log=cfg["log2n"], iq_fp16=cfg["fp16"])
     if mode == "batch":
-        f = gr_fosphor_amd.Fosphor(n_bins=args.bins, max_spectra=F * BATCH, max_batches=F, stream=stream)
+        f = gr_fosphor_amd.Fosphor(stream=stream, **kw)
         sf = None
+        if not args.strict_ordering:
+            f.set_input_ordering(False)		# the ring is written once, before the first call
     else:
-        sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, n_bins=args.bins, max_spectra=F * BATCH)
+        sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw)
         f = sf.f
 
-    def run_steps(n_steps, pos):
-        """submit n_steps batches starting at ring position pos; returns new pos"""
-        done = 0
-        while done < n_steps:
-            nb = min(F, n_steps - done)
-            if pos + nb > ring:
-                pos = 0
-            view = iq[pos * samples_per_batch:(pos + nb) * samples_per_batch]
+    state = {"pos": 0}
+
+    def run_steps(n_steps):
+        for _ in range(n_steps):
+            pos = state["pos"]
+            state["pos"] = (pos + 1) % ring
+            view = iq[pos * step_stream:(pos + 1) * step_stream]
             if mode == "batch":
-                rv = f.process_device(view, nb, BATCH)
+                rv = f.process_device_overlap(view, F, spb, over) if over > 1 else f.process_device(view, F, spb)
                 if rv:
                     raise RuntimeError("process_device -> %d" % rv)
             else:
-                sf.frame(view, nb * BATCH * world, overlap=True, wait_producer=False)	# IQ was generated before the warm-up
-            pos += nb
-            done += nb
+                sf.frame(view, F * spb * world, overlap=True, wait_producer=False)
         if sf is not None:
             sf.flush()
-        return pos
 
     def sync():
+        if f.finish() < 0:
+            raise RuntimeError("device error")
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
     f.finish()				# instance boot (table uploads, initial fills: cl.c:981-995) is not a step
-    pos = run_steps(args.warmup, 0)
+    # untimed pre-conditioning: the same steps until the clocks have settled
+    t0 = time.perf_counter()
+    pre_steps = 0
+    while time.perf_counter() - t0 < args.precondition:
+        run_steps(4)
+        sync()
+        pre_steps += 4
+    precondition_s = time.perf_counter() - t0
+
+    run_steps(args.warmup)
     sync()
-    # timed region: hipEvents around K1 only (events around K2/K3 too cost ~6 % of throughput:
-    # they sit on the critical path of the count/merge streams)
+    # timed region: hipEvents around K1 only (events around K2/K3 too sit on the critical path of the
+    # count/merge stream)
     if not os.environ.get("BENCH_NO_PROFILE"):	# debugging aid: cost of the hipEvents themselves
         f.profile(2)
     t0 = time.perf_counter()
-    run_steps(args.steps, pos)
+    run_steps(args.steps)
     t_submit = time.perf_counter() - t0		# host time to queue everything (host-bound if ~ elapsed)
     sync()
     elapsed = time.perf_counter() - t0
+    busy = f.kernel_busy()
     ms, launches = f.kernel_times()
 
-    # K2 / K3 durations in the pipeline (informational): a short extra pass with events around
-    # every kernel, outside the timed region
-    f.profile(1)
-    run_steps(8 * F, 0)
-    f.kernel_times()
-    run_steps(32 * F, 0)
-    ms_all, n_all = f.kernel_times()
-
-    # K1 alone (same launches, K2/K3 not running beside it): a short extra pass outside the
-    # timed region, reported as roofline.isolated
-    iso = None
-    if mode == "batch":
-        f.set_overlap(False)
-        run_steps(8 * F, 0)
+    ms_all, n_all, iso, twin_ms = [0.0] * 3, [0] * 3, None, None
+    if not args.no_extra_passes:
+        # K2 / K3 durations in the pipeline (informational): a short extra pass with events around
+        # every kernel, outside the timed region
+        f.profile(1)
+        run_steps(2)
+        sync()
         f.kernel_times()
-        run_steps(32 * F, 0)
-        ms_i, n_i = f.kernel_times()
-        f.set_overlap(True)
-        if n_i[0]:
-            iso = ms_i[0] / n_i[0]
+        run_steps(8)
+        sync()
+        ms_all, n_all = f.kernel_times()
+        # K1 alone (same launches, nothing running beside it: one stream), reported as roofline.isolated
+        if mode == "batch":
+            f.set_overlap(False)
+            run_steps(2)
+            sync()
+            f.kernel_times()
+            run_steps(8)
+            sync()
+            ms_i, n_i = f.kernel_times()
+            f.set_overlap(True)
+            if n_i[0]:
+                iso = ms_i[0] / n_i[0]
     f.profile(False)
 
     # the practical ceiling for K1 on this chip: its memory traffic (same loads, order, prefetch depth, stores)
     # without its arithmetic, measured live on the same buffers
-    twin_ms = None
-    if mode == "batch" and not args.no_traffic_twin:
+    if mode == "batch" and args.config == "C2" and not args.no_traffic_twin:
         try:
-            twin_ms = f.traffic_twin(iq[:F * samples_per_batch], F, BATCH, reps=50)
+            sub = min(F, 64)
+            twin_ms = f.traffic_twin(iq[:sub * samples_per_batch], sub, spb, reps=50)
         except Exception:
             twin_ms = None
 
@@ -210,49 +254,76 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_samples = world * args.steps * samples_per_batch
+    total_samples = world * args.steps * F * samples_per_batch
     value = total_samples / elapsed / 1e6
 
     if rank == 0:
-        k1_ms = ms[0] / max(1, launches[0])
-        samples_per_launch = args.steps * samples_per_batch / max(1, launches[0])
-        achieved = BYTES_PER_SAMPLE * samples_per_launch / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_k1_pmc.json")
+        n_k1 = max(1, launches[0])
+        k1_ms = ms[0] / n_k1					# plain average of the individual launch durations
+        k1_busy = busy[0] / n_k1				# union of the K1 intervals / launches
+        samples_per_launch = args.steps * F * samples_per_batch / n_k1
+        alg_bytes = bytes_per_sample * samples_per_launch
+        achieved = alg_bytes / (k1_busy * 1e-3) / 1e9 if k1_busy > 0 else 0.0
+        achieved_plain = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         isolated = None
         if iso:
-            a_i = BYTES_PER_SAMPLE * F * samples_per_batch / (iso * 1e-3) / 1e9
+            a_i = alg_bytes / (iso * 1e-3) / 1e9
             isolated = {"k1_ms_per_launch": iso, "achieved": a_i, "frac": a_i / HBM_PEAK_GBS,
-                        "note": "K1 with K2/K3 not running beside it (single stream), outside the timed region"}
+                        "note": "K1 with nothing running beside it (single stream), outside the timed region"}
+        # HBM bytes per K1 launch from the PMC passes of the same command (tools/profile_round.sh writes the file):
+        # only quoted when it was measured for this very launch shape
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("batches_per_launch") == F and j.get("bins") == args.bins:
+                if (j.get("config") == args.config and j.get("bins") == bins and
+                        abs(j.get("samples_per_launch", 0) - samples_per_launch) < 1):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        k1_name = "k1v2_fft_bin (K1, two waves per spectrum)" if os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2" \
-            else "k1_fft_bin (K1, one wave per spectrum)"
+        k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)", 13: "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
+                   16: "k1h_stage_a + k1h_stage_b (K1, two LDS stages)"}[cfg["log2n"]]
+        if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
+            k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"
+        sub_b = samples_per_launch / samples_per_batch
+        wf_rows = 1024
         out = {
-            "metric": "complex IQ MSamples/s @1024-pt FFT",
+            "metric": "complex IQ MSamples/s @%d-pt FFT" % n_fft,
             "value": value, "unit": "MSamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "C2: 1024-pt FFT, batch=1024 spectra/step/GPU, 1024x%d histogram + waterfall" % args.bins,
-                "mode": mode, "batches_per_launch": F, "ring_batches": ring,
-                "input": "white complex Gaussian sigma=0.05, fp32 IQ resident in HBM (%d MiB ring)" % (ring * 8),
+                "workload": cfg["text"] % dict(bins=bins, bps=F, msamp=F * samples_per_batch >> 20,
+                                               mib=F * samples_per_batch * bytes_per_sample >> 20, sub=int(round(sub_b))),
+                "mode": mode, "batches_per_step": F, "spectra_per_batch": spb, "ring_steps": ring,
+                "k1_launches_per_step": n_k1 / max(1, args.steps),
+                "input": "white complex Gaussian sigma=0.05, %s IQ resident in HBM (%d MiB ring, written once)"
+                         % ("fp16" if cfg["fp16"] else "fp32", iq.numel() * iq.element_size() >> 20),
+                "precondition_s": precondition_s, "precondition_steps": pre_steps,
+                "waterfall": "dead-store rule: a row that a later spectrum of the same call overwrites is not stored, "
+                             "so a step stores the rows of its last %d of %d spectra (the ring ends in the same state; "
+                             "the reference would store all of them)" % (min(wf_rows, F * spb), F * spb),
+                "input_ordering": "strict" if (args.strict_ordering or mode != "batch") else "relaxed",
                 "host_submit_fraction": t_submit / elapsed,
-                "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d steps" % F,
+                "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d batches per GPU" % F,
             },
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
+                         "k1_busy_ms_per_launch": k1_busy, "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
+                         "k1_overlap": (ms[0] / busy[0]) if busy[0] > 0 else None,
+                         "achieved_plain_average": achieved_plain, "frac_plain_average": achieved_plain / HBM_PEAK_GBS,
+                         "accounting": "K1s of consecutive sub-launches run on two streams and overlap at their edges: achieved = "
+                                       "algorithmic bytes of all K1 launches / time with at least one K1 running (union of the "
+                                       "hipEvent intervals); *_plain_average divides by the mean individual duration, which counts "
+                                       "the shared time twice",
+                         "whole_path_frac": value * 1e6 * bytes_per_sample / 1e9 / HBM_PEAK_GBS / max(1, world),
                          "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
                          "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
-                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * samples_per_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "unique_bytes_per_launch": alg_bytes / over,
                          "isolated": isolated,
                          "traffic_twin": None if not twin_ms else {
                              "ms_per_launch": twin_ms,
@@ -260,8 +331,8 @@ def main():
                              "note": "a kernel with K1's loads (same tile order, prefetch depth) and stores but no arithmetic, "
                                      "same buffers: the practical floor the memory system sets for one K1 launch"}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.bins, args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
+            out["cpu_baseline"] = cpu_baseline(bins, args.cpu_seconds)
         # RCCL prints a version banner through C stdio, which would otherwise be flushed after this line
         import ctypes
         ctypes.CDLL(None).fflush(None)

@@ -89,11 +89,14 @@ SIGNATURES = {
     "fosphor_amd_merge": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_profile": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]),
+    "fosphor_amd_kernel_busy": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),
     "fosphor_amd_host_thresholds": (C.c_int, [C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "fosphor_amd_host_twiddle_count": (C.c_int, []),
     "fosphor_amd_host_twiddles": (C.c_int, [C.c_void_p]),
     "fosphor_amd_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_traffic_twin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "fosphor_amd_set_input_ordering": (C.c_int, [C.c_void_p, C.c_int]),
+    "fosphor_amd_wait_input": (C.c_int, [C.c_void_p]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),

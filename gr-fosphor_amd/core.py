@@ -186,6 +186,20 @@ class Fosphor:
     def set_overlap(self, enable):
         return self.L.fosphor_amd_set_overlap(self.h, 1 if enable else 0)
 
+    def set_input_ordering(self, strict):
+        return self.L.fosphor_amd_set_input_ordering(self.h, 1 if strict else 0)
+
+    def wait_input(self):
+        return self.L.fosphor_amd_wait_input(self.h)
+
+    def kernel_busy(self):
+        """ms during which >= 1 kernel of each kind ran (call before kernel_times)"""
+        ms = (C.c_float * 3)()
+        rv = self.L.fosphor_amd_kernel_busy(self.h, C.byref(ms))
+        if rv:
+            raise RuntimeError("fosphor_amd_kernel_busy -> %d" % rv)
+        return list(ms)
+
     def kernel_times(self):
         ms = (C.c_float * 3)()
         n = (C.c_int * 3)()

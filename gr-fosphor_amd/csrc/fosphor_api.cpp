@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "fosphor_internal.h"
@@ -37,7 +39,8 @@ using namespace fosphor_amd;
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
 static const int kMaxN = 65536;
-static const int kSets = 2;		/* intermediate (bin index / partial) sets in rotation */
+static const int kSets = 3;		/* intermediate (bin index / partial) sets in rotation */
+static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
 
@@ -67,13 +70,25 @@ struct fosphor
 	float    *d_win;
 	float2   *d_tw;
 	double   *d_thr;
-	float    *d_wf, *d_hist;
+	float    *d_wf_pp[2], *d_hist;		/* two waterfall rings: a call that rewrites every row targets the other one,
+						 * so its K1s need not wait for the previous call's (see run()) */
+	int       wf_cur;			/* ring the results are in */
+	hipEvent_t ev_wf[2];			/* last K1 that stored rows into ring b */
+	int       wf_used[2];
+	hipStream_t wf_stream[2];
 	float2   *d_spectrum;
 	uint32_t *d_bins_pp[kSets];		/* rotating sets: K1 of launch i+1 overlaps K2/K3 of launch i */
 	float2   *d_partial_pp[kSets];
 	uint32_t *d_bins;			/* current set */
 	float2   *d_partial;
 	int       pp;
+	hipStream_t stream_alt;			/* K1 of every other sub-launch of a device-resident call: consecutive K1s overlap at their edges */
+	int       alt;				/* FOSPHOR_AMD_ALT=0 keeps every K1 on `stream` */
+	int       k23;				/* FOSPHOR_AMD_K23=1: counts and state update fused (k23_strip) */
+	int       k1_seq;
+	int       relaxed;			/* fosphor_amd_set_input_ordering(self, 0) */
+	hipEvent_t ev_in, ev_alt_done;
+	long long sub_samples;			/* samples per sub-launch of a device-resident call */
 	hipStream_t stream2;			/* K2 (and K3 unless pipe3) of the multi-batch path */
 	hipStream_t stream3;			/* K3 of the multi-batch path: K3 of launch i beside K2 of launch i+1 */
 	int       pipe3;			/* FOSPHOR_AMD_PIPE3=0 keeps K3 on stream2 */
@@ -215,7 +230,13 @@ extern "C" void fosphor_release(struct fosphor *self)
 	if (self->stream)
 		(void)hipStreamSynchronize(self->stream);
 	(void)hipFree(self->d_win); (void)hipFree(self->d_tw); (void)hipFree(self->d_thr);
-	(void)hipFree(self->d_wf); (void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
+	(void)hipFree(self->d_wf_pp[0]); (void)hipFree(self->d_wf_pp[1]);
+	(void)hipFree(self->d_hist); (void)hipFree(self->d_spectrum);
+	for (int i = 0; i < 2; i++)
+		if (self->ev_wf[i]) (void)hipEventDestroy(self->ev_wf[i]);
+	if (self->ev_in) (void)hipEventDestroy(self->ev_in);
+	if (self->ev_alt_done) (void)hipEventDestroy(self->ev_alt_done);
+	if (self->stream_alt) { (void)hipStreamSynchronize(self->stream_alt); (void)hipStreamDestroy(self->stream_alt); }
 	for (int i = 0; i < kSets; i++) {
 		(void)hipFree(self->d_bins_pp[i]); (void)hipFree(self->d_partial_pp[i]);
 		if (self->ev_k1_done[i]) (void)hipEventDestroy(self->ev_k1_done[i]);
@@ -326,7 +347,13 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->tw_len = build_twiddles(NULL, self->log2n, NULL);
 	HIP_TRY(hipMalloc((void **)&self->d_tw, sizeof(float2) * self->tw_len), "alloc twiddles");
 	HIP_TRY(hipMalloc((void **)&self->d_thr, sizeof(double) * (self->n_bins + 1)), "alloc thresholds");
-	HIP_TRY(hipMalloc((void **)&self->d_wf, sizeof(float) * (size_t)self->wf_rows * self->n), "alloc waterfall");
+	for (int i = 0; i < 2; i++) {
+		HIP_TRY(hipMalloc((void **)&self->d_wf_pp[i], sizeof(float) * (size_t)self->wf_rows * self->n), "alloc waterfall");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_wf[i], dep_event_flags()), "create event");
+	}
+	HIP_TRY(hipEventCreateWithFlags(&self->ev_in, dep_event_flags()), "create event");
+	HIP_TRY(hipEventCreateWithFlags(&self->ev_alt_done, dep_event_flags()), "create event");
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream_alt, hipStreamNonBlocking), "hipStreamCreate (second FFT stream)");
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
 	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * self->n), "alloc spectrum");
 	for (int i = 0; i < kSets; i++) {
@@ -356,9 +383,17 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
 		self->overlap = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_K1");
-		self->k1_variant = (e && *e == '2') ? 2 : 1;
+		self->k1_variant = (e && *e == '2') ? 2 : (e && *e == '5') ? 5 : (e && *e == '6') ? 6 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
 		self->pipe3 = (e && *e == '1');
+		e = getenv("FOSPHOR_AMD_ALT");
+		self->alt = !(e && *e == '0');
+		/* fused count + merge (k23_strip): 9 % fewer bytes, but its batches are a serial chain (1.6 us each) that
+		 * today costs more than the bytes it saves -- opt-in until that chain is shorter */
+		e = getenv("FOSPHOR_AMD_K23");
+		self->k23 = (e && *e == '1');
+		e = getenv("FOSPHOR_AMD_SUB_LOG2");		/* tuning: log2 of the samples per sub-launch */
+		self->sub_samples = 1LL << ((e && atoi(e) >= 14 && atoi(e) <= 34) ? atoi(e) : kSubSamplesLog2);
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
@@ -473,6 +508,7 @@ static int sync_all(struct fosphor *self)
 {
 	int rv = 0;
 	if (self->stream  && hipStreamSynchronize(self->stream)  != hipSuccess) rv = -EIO;
+	if (self->stream_alt && hipStreamSynchronize(self->stream_alt) != hipSuccess) rv = -EIO;
 	if (self->stream2 && hipStreamSynchronize(self->stream2) != hipSuccess) rv = -EIO;
 	if (self->stream3 && hipStreamSynchronize(self->stream3) != hipSuccess) rv = -EIO;
 	return rv;
@@ -524,7 +560,8 @@ static int prepare(struct fosphor *self)
 	if (self->state == ST_BOOTING) {
 		const float noise_floor = -self->power.offset;
 		HIP_TRY(launch_fill((float *)self->d_spectrum, noise_floor, (size_t)4 * self->n, self->stream), "fill spectrum");
-		HIP_TRY(launch_fill(self->d_wf, noise_floor, (size_t)self->wf_rows * self->n, self->stream), "fill waterfall");
+		for (int i = 0; i < 2; i++)
+			HIP_TRY(launch_fill(self->d_wf_pp[i], noise_floor, (size_t)self->wf_rows * self->n, self->stream), "fill waterfall");
 		HIP_TRY(launch_fill(self->d_hist, 0.0f, (size_t)self->n_bins * self->n, self->stream), "fill histogram");
 	}
 	return 0;
@@ -532,14 +569,26 @@ error:
 	return -EIO;
 }
 
-static int pick_tile(int total)
+/* Spectra per K1 wave (N = 1024) / per work-group pass (other lengths).  One tile = one row of live / max
+ * partials (8 B per column), so longer tiles mean fewer intermediate bytes: 64 spectra per wave is 0.125 B per
+ * sample written and read back, 16 was 0.5.  A tile never straddles a batch (K2 weights whole tiles). */
+static int pick_tile(const struct fosphor *self, int total, int batch)
 {
 	const char *e = getenv("FOSPHOR_AMD_TILE");
-	if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16))
-		return atoi(e);
-	/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
-	if (total / 16 >= 2048) return 16;
-	if (total / 8 >= 2048) return 8;
+	const int v = e ? atoi(e) : 0;
+	if (v >= 4 && v <= 128 && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
+		return v;
+	if (self->log2n != 10 || self->bins16) {
+		/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
+		if (total / 16 >= 2048) return 16;
+		if (total / 8 >= 2048) return 8;
+		return 4;
+	}
+	/* 1024 waves (one 4-wave work-group per CU) per launch: consecutive launches overlap on alternating
+	 * streams, so two of them fill the chip's 512 work-group slots */
+	for (int t = 64; t >= 8; t >>= 1)
+		if (batch % t == 0 && total / t >= 1024)
+			return t;
 	return 4;
 }
 
@@ -567,7 +616,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->thr = self->d_thr;
 	k1->bins = self->d_bins;
 	k1->partial = self->d_partial;
-	k1->wf = self->d_wf;
+	k1->wf = self->d_wf_pp[self->wf_cur];
 	k1->fft_out = NULL;
 	k1->dbg = self->d_dbg;
 	k1->total = total;
@@ -584,7 +633,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : (self->log2n == 16 ? 4 : 3);
 	k1->scratch = self->d_scratch;
 	k1->iq_half = self->iq_half;
-	if (k1->variant == 1 && (k1->hop & 1))
+	if ((k1->variant == 1 || k1->variant == 5 || k1->variant == 6) && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
 
@@ -700,72 +749,188 @@ error:
 	return -EIO;
 }
 
-static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch, int hop = 0)
+/* Counts and state update fused (k23_strip): N = 1024 path with 8-bit bin indices, batch <= 1024. */
+static int k23_ok(const struct fosphor *self, int batch)
+{
+	return self->k23 && self->log2n == 10 && !self->bins16 && batch <= 1024 && batch <= kRiseMax;
+}
+
+static int run_k23(struct fosphor *self, int n_batches, int batch, int tile, hipStream_t st)
+{
+	K23Params k;
+	if (ensure_rise_table(self, batch, st) <= 0 || k3_stream_enter(self, st))
+		return -EIO;
+	memset(&k, 0, sizeof(k));
+	k.bins = self->d_bins; k.partial = self->d_partial;
+	k.hist = self->d_hist; k.spectrum = self->d_spectrum;
+	k.hc_export = self->d_hc_export;
+	k.rise = self->d_rise;
+	k.n = self->n; k.n_bins = self->n_bins; k.n_batches = n_batches; k.batch = batch; k.tile = tile;
+	k.log2_w = (float)log2((double)(1.0f - self->alpha));
+	k.alpha = self->alpha;
+	k.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
+	prof_begin(self, 1, st);
+	HIP_TRY(launch_k23(k, st), "launch count+merge");
+	prof_end(self, st);
+	return 0;
+error:
+	return -EIO;
+}
+
+/* Waterfall ring ownership between K1s that may run on different streams: a K1 that stores rows into ring b
+ * follows the previous K1 that did. */
+static int wf_enter(struct fosphor *self, hipStream_t ks)
+{
+	const int b = self->wf_cur;
+	if (self->wf_used[b] && self->wf_stream[b] != ks && hipStreamWaitEvent(ks, self->ev_wf[b], 0) != hipSuccess)
+		return -EIO;
+	return 0;
+}
+
+static int wf_leave(struct fosphor *self, hipStream_t ks)
+{
+	const int b = self->wf_cur;
+	if (hipEventRecord(self->ev_wf[b], ks) != hipSuccess)
+		return -EIO;
+	self->wf_used[b] = 1;
+	self->wf_stream[b] = ks;
+	return 0;
+}
+
+/* n_batches consecutive batches of `batch` spectra.  device_call: the samples are the caller's device buffer
+ * (fosphor_amd_process_device*), which may be cut into sub-launches whose K1s alternate between two streams. */
+static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch, int hop = 0, int device_call = 0)
 {
 	const int total = n_batches * batch;
-	const int tile = pick_tile(total);
+	const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
+	const int hop_samples = hop ? hop : self->n;
 	hipStream_t st2 = self->overlap ? self->stream2 : self->stream;
 	/* third stream: only the 16-bit count path has a second hit-count set */
 	const int three = self->overlap && self->pipe3 && batch <= 1024 && self->rise_ok(batch);
 	hipStream_t st3 = three ? self->stream3 : st2;
-	K1Params k1;
-	int set, hset = 0;
+	const int did_prep = self->win_dirty || self->thr_dirty || self->state == ST_BOOTING;
+	const int wf_first_global = total > self->wf_rows ? total - self->wf_rows : 0;
+	int sub_b, n_sub, use_alt, used_alt = 0;
+	/* measurement only (results are wrong): FOSPHOR_AMD_DBG_SKIP bit 0 = no K1, bit 1 = no count / merge */
+	static const int dbg_skip = [] { const char *e = getenv("FOSPHOR_AMD_DBG_SKIP"); return e ? atoi(e) : 0; }();
 
 	if (prepare(self))
 		return -EIO;
 
-	/* Pipeline: K1 (VALU-bound) of this launch runs on `stream` while K2/K3 (memory- and
-	 * latency-bound) of the previous launch still run on `stream2`; the bin-index / partial
-	 * intermediates ping-pong between two sets.  K1 may reuse a set once the K2 that read
-	 * it has finished; K2 starts when its K1 has finished.  K3 (one work-group per CU beside K1,
-	 * like K2) gets a third stream and the hit counts a second set, so K3 of launch i runs
-	 * beside K2 of launch i+1; K3s stay in launch order on that stream, so the persistent state
-	 * sees the batches in order. */
-	set = self->pp;
-	self->pp = (self->pp + 1) % kSets;
-	self->d_bins = self->d_bins_pp[set];
-	self->d_partial = self->d_partial_pp[set];
-	if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
-		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
+	/* Sub-launches.  A call is cut into pieces of about sub_samples samples (64 reference batches): the
+	 * bin-index / partial intermediates of a piece stay small enough to be consumed by K2 out of the Infinity
+	 * Cache, and the pipeline below overlaps K2/K3 of piece j with K1 of piece j+1 INSIDE one call.
+	 *   K1 (j)   on `stream` / `stream_alt` alternately: K1 of piece j+1 is dispatched while K1 of piece j
+	 *            drains, so no CU idles between them (kernel tail, dispatch gap and prologue overlap);
+	 *   K2 (j)   on stream2 once K1 (j) has finished; K3 (j) follows it there, so the persistent state sees the
+	 *            batches in order.
+	 * The intermediates rotate among kSets sets: K1 may reuse a set once the K2 that read it has finished. */
+	sub_b = (int)(self->sub_samples / ((long long)batch * self->n));
+	if (sub_b < 1) sub_b = 1;
+	if (sub_b > n_batches) sub_b = n_batches;
+	n_sub = (n_batches + sub_b - 1) / sub_b;
+	sub_b = (n_batches + n_sub - 1) / n_sub;
+	use_alt = self->overlap && self->alt && device_call && (n_sub > 1 || self->relaxed);
 
-	fill_k1(self, &k1, d_iq, total, tile, self->wf_pos,
-	        total > self->wf_rows ? total - self->wf_rows : 0, hop);
-	prof_begin(self, 0, self->stream);
-	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
-	prof_end(self, self->stream);
+	/* A call that stores every row of the ring does so in the other ring: its K1s then owe nothing to the
+	 * row stores of the calls before it.  Otherwise the untouched rows must survive: same ring. */
+	if (use_alt && total >= self->wf_rows)
+		self->wf_cur ^= 1;
+	if (use_alt && (did_prep || !self->relaxed)) {
+		/* the second FFT stream sees what the caller (and prepare()) queued on `stream` */
+		HIP_TRY(hipEventRecord(self->ev_in, self->stream), "record input ready");
+		HIP_TRY(hipStreamWaitEvent(self->stream_alt, self->ev_in, 0), "second FFT stream waits for the input");
+	}
 
-	if (self->overlap) {
-		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
-		HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
+	for (int b0 = 0; b0 < n_batches; b0 += sub_b) {
+		const int nb = (n_batches - b0 < sub_b) ? n_batches - b0 : sub_b;
+		const int t0 = b0 * batch, sub_total = nb * batch;
+		const int tile = pick_tile(self, sub_total, batch);
+		hipStream_t ks = self->stream;
+		K1Params k1;
+		int set, hset = 0, wf_first, stores_rows;
+
+		if (use_alt && (self->k1_seq++ & 1)) {
+			ks = self->stream_alt;
+			used_alt = 1;
+		}
+		set = self->pp;
+		self->pp = (self->pp + 1) % kSets;
+		self->d_bins = self->d_bins_pp[set];
+		self->d_partial = self->d_partial_pp[set];
+		if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
+			HIP_TRY(hipStreamWaitEvent(ks, self->ev_set_free[set], 0), "wait for intermediate set");
+
+		wf_first = wf_first_global - t0;
+		if (wf_first < 0) wf_first = 0;
+		stores_rows = wf_first < sub_total;
+		if (!stores_rows) wf_first = sub_total;
+		fill_k1(self, &k1, (const char *)d_iq + (size_t)t0 * hop_samples * sample_bytes, sub_total, tile,
+		        (self->wf_pos + t0) & (self->wf_rows - 1), wf_first, hop);
+		if (stores_rows && wf_enter(self, ks))
+			return -EIO;
+		prof_begin(self, 0, ks);
+		if (!(dbg_skip & 1))
+			HIP_TRY(launch_k1(k1, ks), "launch fft_bin");
+		prof_end(self, ks);
+		if (stores_rows && wf_leave(self, ks))
+			return -EIO;
+
+		if (self->overlap) {
+			HIP_TRY(hipEventRecord(self->ev_k1_done[set], ks), "record K1 done");
+			HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
+		}
+		if (dbg_skip & 2) {
+			if (self->overlap) {
+				HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+				self->set_used[set] = 1;
+			}
+			continue;
+		}
+		if (k23_ok(self, batch)) {
+			if (drain_h_sets(self, st2) || run_k23(self, nb, batch, tile, st2))
+				return -EIO;
+			if (self->overlap) {
+				HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+				self->set_used[set] = 1;
+			}
+			self->last_batches = nb;
+			continue;
+		}
+		if (three) {
+			hset = self->hset;
+			self->hset ^= 1;
+			if (self->hset_used[hset])
+				HIP_TRY(hipStreamWaitEvent(st2, self->ev_h_free[hset], 0), "wait for hit-count set");
+		} else if (drain_h_sets(self, st2)) {
+			return -EIO;
+		}
+		if (run_count(self, nb, batch, tile, 0, 0, batch, st2, 1, hset))
+			return -EIO;
+		if (self->overlap) {
+			HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+			self->set_used[set] = 1;
+		}
+		if (three) {
+			HIP_TRY(hipEventRecord(self->ev_k2_done[hset], st2), "record K2 done");
+			HIP_TRY(hipStreamWaitEvent(st3, self->ev_k2_done[hset], 0), "K3 waits for K2");
+		}
+		if (run_merge(self, nb, batch, 0, st3, 1, hset))
+			return -EIO;
+		if (three) {
+			HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
+			self->hset_used[hset] = 1;
+		}
+		self->last_batches = nb;
 	}
-	if (three) {
-		hset = self->hset;
-		self->hset ^= 1;
-		if (self->hset_used[hset])
-			HIP_TRY(hipStreamWaitEvent(st2, self->ev_h_free[hset], 0), "wait for hit-count set");
-	} else if (drain_h_sets(self, st2)) {
-		return -EIO;
-	}
-	if (run_count(self, n_batches, batch, tile, 0, 0, batch, st2, 1, hset))
-		return -EIO;
-	if (self->overlap) {
-		HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
-		self->set_used[set] = 1;
-	}
-	if (three) {
-		HIP_TRY(hipEventRecord(self->ev_k2_done[hset], st2), "record K2 done");
-		HIP_TRY(hipStreamWaitEvent(st3, self->ev_k2_done[hset], 0), "K3 waits for K2");
-	}
-	if (run_merge(self, n_batches, batch, 0, st3, 1, hset))
-		return -EIO;
-	if (three) {
-		HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
-		self->hset_used[hset] = 1;
+	if (used_alt && !self->relaxed) {
+		/* what the caller queues on `stream` next (e.g. refilling the sample buffer) follows every K1 */
+		HIP_TRY(hipEventRecord(self->ev_alt_done, self->stream_alt), "record second FFT stream");
+		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_alt_done, 0), "stream waits for the second FFT stream");
 	}
 	self->last_hc16 = (batch <= 1024 && batch <= kRiseMax);
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
-	self->last_batches = n_batches;
 	self->last_slot0 = 0;
 	self->state = ST_PENDING;
 	return 0;
@@ -779,7 +944,7 @@ extern "C" int fosphor_amd_process_device(struct fosphor *self, const void *d_sa
 		return -EINVAL;
 	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
 		return -EINVAL;
-	return run(self, d_samples, n_batches, batch);
+	return run(self, d_samples, n_batches, batch, 0, 1);
 }
 
 /* overlap_cc (lib/overlap_cc_impl.cc:48-79) emits wlen-sample windows whose starts advance
@@ -795,7 +960,7 @@ extern "C" int fosphor_amd_process_device_overlap(struct fosphor *self, const vo
 		return -EINVAL;
 	if ((long long)n_batches * batch > self->max_spectra || n_batches > self->max_batches)
 		return -EINVAL;
-	return run(self, d_samples, n_batches, batch, self->n / overlap);
+	return run(self, d_samples, n_batches, batch, self->n / overlap, 1);
 }
 
 extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
@@ -816,13 +981,15 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	 * are copied into a pinned ring slot before returning, and the slot is recycled only when
 	 * its H2D copy has completed. */
 	k = self->stage_idx;
-	if (!self->h_stage[k]) {
+	/* (each piece behind its own check: fosphor_amd_process_pinned shares d_stage / stage_free) */
+	if (!self->h_stage[k])
 		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sample_bytes * self->stage_samples, hipHostMallocDefault), "alloc pinned staging");
+	if (!self->d_stage[k])
 		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
+	if (!self->stage_free[k])
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
-	} else {
+	else
 		HIP_TRY(hipEventSynchronize(self->stage_free[k]), "wait staging slot");
-	}
 	memcpy(self->h_stage[k], samples, sample_bytes * (size_t)len);
 	HIP_TRY(hipMemcpyAsync(self->d_stage[k], self->h_stage[k], sample_bytes * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples");
 	{
@@ -846,10 +1013,10 @@ extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samp
 		return -EINVAL;		/* cl.c:882-886 */
 
 	k = self->stage_idx;
-	if (!self->d_stage[k]) {
+	if (!self->d_stage[k])
 		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
+	if (!self->stage_free[k])
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
-	}
 	if (!self->upload_done)
 		HIP_TRY(hipEventCreateWithFlags(&self->upload_done, hipEventDisableTiming), "create upload event");
 	/* d_stage[k] was last read by a K1 queued earlier on the same stream: ordered by the stream */
@@ -898,7 +1065,7 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 {
 	if (!self || !out)
 		return -EINVAL;
-	out->d_waterfall = self->d_wf;
+	out->d_waterfall = self->d_wf_pp[self->wf_cur];
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
 	out->d_hitcount  = self->last_hc16 ? self->d_hc_export
@@ -1004,7 +1171,7 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	if (self->overlap && self->set_used[set])
 		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_set_free[set], 0), "wait for intermediate set");
 
-	tile = pick_tile(n_local);
+	tile = pick_tile(self, n_local, n_local);
 	/* global spectrum index tau = t_offset + t stores its row iff tau >= total_batch - wf_rows */
 	wf_first = total_batch - self->wf_rows - t_offset;
 	if (wf_first < 0) wf_first = 0;
@@ -1038,6 +1205,10 @@ error:
 extern "C" int fosphor_amd_set_partial_slot(struct fosphor *self, int slot)
 {
 	if (!self || slot < 0 || slot >= self->max_batches)
+		return -EINVAL;
+	/* the per-chunk 16-bit count slabs of a multi-chunk shard live in the upper half of the hit-count
+	 * array (run_count), i.e. in the memory of the 32-bit slots max_batches/2 and above */
+	if (self->max_batches >= 4 && slot >= self->max_batches / 2)
 		return -EINVAL;
 	self->slot = slot;
 	return 0;
@@ -1099,6 +1270,43 @@ extern "C" int fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int l
 	return 0;
 }
 
+/* Time during which at least one kernel of each kind was running (union of the recorded intervals), from the
+ * same events fosphor_amd_kernel_times sums.  K1s of consecutive sub-launches overlap on two streams, so the sum
+ * of their individual durations counts the shared time twice; the union is what a launch costs.  Call before
+ * fosphor_amd_kernel_times (which resets). */
+extern "C" int fosphor_amd_kernel_busy(struct fosphor *self, float busy_ms[3])
+{
+	if (!self)
+		return -EINVAL;
+	if (sync_all(self))
+		return -EIO;
+	for (int kind = 0; kind < 3; kind++) {
+		std::vector<std::pair<float, float> > iv;
+		for (size_t i = 0; i + 1 < self->ev_used; i += 2) {
+			float a = 0.0f, b = 0.0f;
+			if (self->ev_kind[i / 2] != kind)
+				continue;
+			if (hipEventElapsedTime(&a, self->ev_pool[0], self->ev_pool[i]) != hipSuccess ||
+			    hipEventElapsedTime(&b, self->ev_pool[0], self->ev_pool[i + 1]) != hipSuccess)
+				continue;
+			iv.push_back(std::make_pair(a, b));
+		}
+		std::sort(iv.begin(), iv.end());
+		float busy = 0.0f, cur_a = 0.0f, cur_b = -1.0f;
+		for (size_t i = 0; i < iv.size(); i++) {
+			if (cur_b < cur_a || iv[i].first > cur_b) {
+				if (cur_b >= cur_a) busy += cur_b - cur_a;
+				cur_a = iv[i].first; cur_b = iv[i].second;
+			} else if (iv[i].second > cur_b) {
+				cur_b = iv[i].second;
+			}
+		}
+		if (cur_b >= cur_a) busy += cur_b - cur_a;
+		busy_ms[kind] = busy;
+	}
+	return 0;
+}
+
 /* Measurement hook: the memory traffic of one K1 launch (same loads, same stores, same order)
  * without its arithmetic, on this instance's buffers; average of `reps` launches in ms.  The
  * intermediates of the current set are overwritten (call between launches, results unaffected:
@@ -1114,7 +1322,7 @@ extern "C" int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samp
 		return -EINVAL;
 	if (fosphor_amd_finish(self) < 0 || prepare(self))
 		return -EIO;
-	fill_k1(self, &k1, d_samples, total, pick_tile(total), 0, total);
+	fill_k1(self, &k1, d_samples, total, pick_tile(self, total, batch), 0, total);
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
 		return -EIO;
 	for (int i = 0; i < 3; i++)
@@ -1204,8 +1412,33 @@ extern "C" int fosphor_amd_set_overlap(struct fosphor *self, int enable)
 	if (fosphor_amd_finish(self) < 0)
 		return -EIO;
 	self->overlap = enable ? 1 : 0;
-	self->set_used[0] = self->set_used[1] = 0;
+	for (int i = 0; i < kSets; i++)
+		self->set_used[i] = 0;
 	self->hset_used[0] = self->hset_used[1] = 0;
+	return 0;
+}
+
+/* strict = 1 (default): a device-resident call behaves like work queued on `stream`: its K1s start after what
+ * the caller queued there before the call, and what the caller queues there afterwards starts after them.
+ * strict = 0: no ordering against `stream` in either direction (the caller guarantees the samples are complete
+ * before the call and keeps them until fosphor_amd_finish() or fosphor_amd_wait_input()); consecutive calls then
+ * overlap at their edges like the sub-launches inside one call. */
+extern "C" int fosphor_amd_set_input_ordering(struct fosphor *self, int strict)
+{
+	if (!self)
+		return -EINVAL;
+	self->relaxed = strict ? 0 : 1;
+	return 0;
+}
+
+/* Makes `stream` wait for every K1 queued so far (the readers of the callers' sample buffers). */
+extern "C" int fosphor_amd_wait_input(struct fosphor *self)
+{
+	if (!self)
+		return -EINVAL;
+	if (hipEventRecord(self->ev_alt_done, self->stream_alt) != hipSuccess ||
+	    hipStreamWaitEvent(self->stream, self->ev_alt_done, 0) != hipSuccess)
+		return -EIO;
 	return 0;
 }
 

@@ -108,7 +108,24 @@ struct K3Params {
 	float live_decay;		/* (1-alpha)^batch */
 };
 
+/* K23: hit counts AND state update in one kernel (N = 1024 path, 8-bit bin indices, batch <= 1024).
+ * One work-group owns 4 columns for the whole launch and walks the batches in order: count the batch's
+ * spectra into LDS, then apply rise/decay to its 4 x n_bins cells (state in registers), live EMA and max-hold
+ * to its 4 columns.  The per-batch hit counts never leave the CU (K2 -> K3 moved 0.5 B per sample each way). */
+struct K23Params {
+	const uint32_t *bins;		/* [total/4][N] */
+	const float2   *partial;	/* [total/tile][N] */
+	float    *hist;			/* [n_bins][N] */
+	float2   *spectrum;		/* [2][N] */
+	uint32_t *hc_export;		/* [n_bins][N] counts of the launch's last batch */
+	const float2 *rise;		/* [batch+1] (d, e) per hit count */
+	int   n, n_bins, n_batches, batch, tile;
+	float log2_w;			/* log2(1 - alpha) */
+	float alpha, live_decay;	/* display.cl:210-211 */
+};
+
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
+hipError_t launch_k23(const K23Params &p, hipStream_t s);
 hipError_t launch_k1_traffic_twin(const K1Params &p, hipStream_t s);
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s);
 hipError_t launch_k2b(const K2bParams &p, hipStream_t s);

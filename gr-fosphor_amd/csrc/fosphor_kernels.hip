@@ -281,6 +281,9 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #ifndef K1_LOAD16
 #define K1_LOAD16 1			/* 1: 16-byte IQ loads, lane L owns pass-1 items 2L and 2L+1; 0: 8-byte loads, items L and L+64 */
 #endif
+#ifndef K1_UNIFORM
+#define K1_UNIFORM 1			/* wave-uniform control values in SGPRs, in-place Horner, one branch for the row stores */
+#endif
 #ifndef K1_TW3_LDS
 #define K1_TW3_LDS 0			/* pass-3 twiddles from an LDS table instead of registers */
 #endif
@@ -336,7 +339,11 @@ void k1_fft_bin(const K1Params p)
 #endif
 
 	const int lane   = threadIdx.x & 63;
+#if K1_UNIFORM
+	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);	/* tile, spectrum index, row predicate: SGPRs */
+#else
 	const int wv     = threadIdx.x >> 6;
+#endif
 	const int ntiles = p.total / p.tile;
 	const int stride = gridDim.x * 4;		/* waves in the grid */
 #if K1_TIMING
@@ -579,6 +586,21 @@ void k1_fft_bin(const K1Params p)
 				}
 			}
 
+#if K1_UNIFORM
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				/* Horner form of display.cl:149-150, in place (v_fma with the accumulator as destination:
+				 * the compiler's v_fmac into the dying l2 register costs a v_mov per column) */
+				asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
+				vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
+			}
+			if (t >= p.wf_first) {				/* uniform: one scalar branch */
+				float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
+#pragma unroll
+				for (int m = 0; m < 16; m++)
+					wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
+			}
+#else
 			const bool store_row = (t >= p.wf_first);
 			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
 #pragma unroll
@@ -588,6 +610,7 @@ void k1_fft_bin(const K1Params p)
 				if (store_row)
 					wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
 			}
+#endif
 			K1_STAMP(6);		/* epilogue */
 		}
 
@@ -616,6 +639,334 @@ void k1_fft_bin(const K1Params p)
 		p.dbg[w * 8 + 5] = wall_clock64();
 	}
 #endif
+}
+
+/* ------------------------------------------------------------------------ */
+/* K1, two spectra ahead                                                      */
+/* ------------------------------------------------------------------------ */
+/* Same wave-per-spectrum mapping, arithmetic, LDS exchange and outputs as k1_fft_bin, with the changes that
+ * come from measuring it: a wave of k1_fft_bin has ONE spectrum (8 KiB) of IQ in flight and drains the whole
+ * vector-memory queue (`s_waitcnt vmcnt(0)`: the previous spectrum's stores included) before every spectrum;
+ * at the ~3 us the memory system needs under load that round trip bounds it (2048 waves x 8 KiB / 3 us =
+ * 5.5 TB/s at best, 4.5 TB/s with the compute in the loop) -- not bandwidth, and not the VALU (40 % busy).
+ *   - the IQ of spectrum k+2 is requested while spectrum k is computed: two register sets, the loop unrolled by
+ *     two so that neither is ever copied; 16 KiB per wave in flight;
+ *   - the requests are inline-asm loads and the waits are hand-counted `s_waitcnt vmcnt(N)`: the vector-memory
+ *     queue retires in order, so "at most N operations outstanding" with N = the operations issued AFTER the
+ *     wanted request means exactly "the wanted request has landed", and the younger request and the bin-index
+ *     stores stay in flight (the compiler's own counting has to assume that a conditional request or store did
+ *     not happen and falls back to vmcnt(0));
+ *   - the registers of the second set come from the pass-2/3 twiddles, which move to a work-group LDS table
+ *     (14 ds_read_b64 per spectrum);
+ *   - everything uniform over the wave (tile, spectrum index, row-store predicate) is forced into SGPRs, which
+ *     turns 16 exec-mask save/restore sequences per spectrum into one scalar branch. */
+
+/* the 8 x 1 KiB of one spectrum: lane L gets elements (2L, 2L+1) + 128 q in set[q]; non-temporal (read once) */
+static __device__ __forceinline__ void iq_request(v4f (&q)[8], const float2 *src)
+{
+	const char *a = reinterpret_cast<const char *>(src);
+	const char *b = a + 4096;
+	asm volatile("global_load_dwordx4 %0, %1, off nt"             : "=v"(q[0]) : "v"(a) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(q[1]) : "v"(a) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(q[2]) : "v"(a) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(q[3]) : "v"(a) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off nt"             : "=v"(q[4]) : "v"(b) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(q[5]) : "v"(b) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(q[6]) : "v"(b) : "memory");
+	asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(q[7]) : "v"(b) : "memory");
+}
+
+/* The set's registers are tied to a point behind the hand-counted wait, so that no use of them can be
+ * scheduled above it (volatile asm statements keep their order). */
+static __device__ __forceinline__ void iq_landed(v4f (&q)[8])
+{
+	asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
+	             :: "memory");
+}
+
+/* every value of x is computed before anything that follows (the next request reuses the set's registers:
+ * without this the scheduler sinks window multiplies below the loads and the allocator pays with 32 copies) */
+static __device__ __forceinline__ void pin16(const v2f (&x)[16])
+{
+	asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+	             "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]) : "memory");
+}
+
+template <bool WRITE_FFT, int DEPTH>	/* DEPTH: spectra requested ahead (2, or 1 = one register set: 208 VGPRs) */
+__global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
+void k1d_fft_bin(const K1Params p)
+{
+	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
+	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles */
+	__shared__ float win_tab[kN];			/* window */
+	__shared__ v2f   tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
+	__shared__ v2f   tw2_tab[7][8];			/* pass-2 twiddles [n-1][k] */
+
+	const int lane   = threadIdx.x & 63;
+	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int ntiles = p.total / p.tile;
+	const int stride = gridDim.x * 4;		/* waves in the grid */
+	const int tile0  = blockIdx.x * 4 + wv;
+	const int T      = p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+
+	for (int i = threadIdx.x; i < kN; i += 256)
+		win_tab[i] = p.win[i];
+	for (int i = threadIdx.x; i < 512; i += 256)
+		tw4_tab[i] = twg[kTw4Off + i];
+	for (int i = threadIdx.x; i < 7 * 64; i += 256)
+		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
+	if (threadIdx.x < 56)
+		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
+	__syncthreads();				/* the only block-wide barrier */
+
+	if (tile0 >= ntiles)
+		return;					/* whole wave leaves */
+
+	v2f *buf = lds[wv];
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+
+	/* swizzled LDS addressing, as in k1_fft_bin */
+	const int rd_even = lane ^ ((lane >> 3) & 7);
+	const int rd_odd  = rd_even ^ 8;
+	const int st1a    = (16 * lane) ^ ((2 * lane) & 15);
+	const int st1b    = (16 * lane + 8) ^ ((2 * lane + 1) & 15);
+	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);
+
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	/* the k-th spectrum of this wave: tiles tile0, tile0 + stride, ... in order, T spectra each */
+	auto spectrum_of = [&](int k, int *tile_out) -> int {
+		const int j = k / T;
+		const int tile = tile0 + j * stride;
+		*tile_out = tile;
+		return tile * T + (k - j * T);
+	};
+	/* ALWAYS eight loads (the hand-counted waits rely on it): past the end of this wave's work the request
+	 * re-reads the launch's first spectrum (cache hits) and is never used */
+	auto request = [&](v4f (&q)[8], int k) {
+		int tile;
+		int t = spectrum_of(k, &tile);
+		if (tile >= ntiles)
+			t = 0;
+		iq_request(q, p.iq + (size_t)t * p.hop + 2 * lane);
+	};
+
+	float live[16], vmax[16];
+	uint32_t pack[16];
+
+	auto body = [&](v4f (&xq)[8], int k, int tile, int t, const bool odd) {
+		const int g = t - tile * T;		/* position in the tile */
+		const int u = g & 3;
+		v2f x[16];
+
+		if (g == 0) {
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				live[m] = 0.0f;
+				vmax[m] = vmax_init;
+			}
+		}
+		if (u == 0) {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				pack[m] = 0;
+		}
+
+		/* Operations issued after this set's request: the other set's request (8) and, when the spectrum
+		 * before this one or the one before that closed a group of four (u == 3), its 16 bin-index stores.
+		 * (The rare row / partial stores only make the wait longer than needed.) */
+		if (DEPTH == 2) {
+			if (u < 2)
+				asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+		} else {
+			/* one set: only the 16 bin-index stores of a group that just closed are younger */
+			if (u == 0)
+				asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		iq_landed(xq);
+
+		/* window (fft.cl:415-417); taps fetched as pairs */
+#pragma unroll
+		for (int q = 0; q < 8; q++) {	/* x[2q], x[2q+1] = elements 2L + 128q, 2L + 1 + 128q */
+			const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * q]);
+			x[2 * q]     = mul_bcast_lo(v2f{ xq[q].x, xq[q].y }, w);
+			x[2 * q + 1] = mul_bcast_hi(v2f{ xq[q].z, xq[q].w }, w);
+		}
+		/* this register set is free again: request the spectrum after next */
+		pin16(x);
+		request(xq, k + DEPTH);
+
+		/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) */
+#pragma unroll
+		for (int v = 0; v < 2; v++) {
+			v2f r[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = x[v + 2 * j];
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
+		wave_lds_sync();
+
+		/* ---- pass 2: radix 8, p = 8 (fft.cl:422-423) */
+		{
+			v2f tw2[7];
+#pragma unroll
+			for (int n = 0; n < 7; n++)
+				tw2[n] = tw2_tab[n][lane & 7];
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				v2f r[8];
+				r[0] = x[v];
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					buf[(st2 ^ (9 * jj)) + 512 * v] = r[R8_PERM(jj)];
+			}
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
+		wave_lds_sync();
+
+		/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426); the third exchange is register renaming */
+		{
+			v2f y[16];
+			v2f tw3[7];
+#pragma unroll
+			for (int n = 0; n < 7; n++)
+				tw3[n] = tw3_tab[n][lane];
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				v2f r[8];
+				r[0] = x[v];
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					y[jj + 8 * v] = r[R8_PERM(jj)];
+			}
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				x[m] = y[m];
+		}
+
+		/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) */
+#pragma unroll
+		for (int c = 0; c < 8; c++) {
+			v2f a = x[c];
+			v2f b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);
+			DFT2(a, b);
+			x[c] = a;
+			x[c + 8] = b;
+		}
+
+		if (WRITE_FFT) {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * m] = x[m];
+		}
+
+		/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) */
+		float    l2[16];
+		uint32_t amb = 0;
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			uint32_t ab;
+			const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
+			amb = amb > ab ? amb : ab;
+			pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+		}
+		if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				const float v = __builtin_fmaf(bk.A, l2[m], bk.C);
+				const float r = __builtin_rintf(v);
+				const float a = __builtin_fmaf(__builtin_fabsf(l2[m]), bk.kappa, __builtin_fabsf(v - r));
+				if (!(a <= bk.amb)) {
+					const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
+					float nl2;
+					const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
+					pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
+					l2[m] = nl2;
+				}
+			}
+		}
+
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			/* Horner form of display.cl:149-150, in place (v_fma with the accumulator as destination) */
+			asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
+			vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
+		}
+		if (t >= p.wf_first) {				/* uniform: one scalar branch */
+			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
+		}
+		if (u == 3) {
+			/* 4 spectra x 1 column per dword, coalesced 256 B per instruction */
+			uint32_t *dst = p.bins + (size_t)(t >> 2) * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				dst[64 * m] = pack[m];
+		}
+		if (g == T - 1) {
+			/* leave the log2 domain; an untouched max is exactly -1000 */
+			float2 *pp = p.partial + (size_t)tile * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				pp[64 * m] = make_float2(live[m] * F_HALF_LOG10_2,
+				                         (vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
+		}
+	};
+
+	v4f xa[8], xb[8];
+	request(xa, 0);
+	if (DEPTH == 2)
+		request(xb, 1);
+	{
+		/* 16 stores behind the two requests, as every group of four spectra leaves them (the wait counts
+		 * of the first two spectra then hold from the start); the real indices overwrite these zeros */
+		uint32_t *dst = p.bins + (size_t)((tile0 * T) >> 2) * kN + lane;
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			dst[64 * m] = 0;
+	}
+	/* T is a multiple of 4, so neither a tile nor a group of four ends between the halves of an iteration */
+	for (int k = 0; ; k += 2) {
+		int tile;
+		const int t = spectrum_of(k, &tile);
+		if (tile >= ntiles)
+			break;
+		body(xa, k, tile, t, false);
+		if (DEPTH == 2)
+			body(xb, k + 1, tile, t + 1, true);
+		else
+			body(xa, k + 1, tile, t + 1, true);
+	}
+	/* the two requests still in flight target registers: they must land before the wave ends */
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1359,12 +1710,23 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		return launch_k1h(p, s);
 	const int tiles = p.total / p.tile;
 	if (p.variant == 3) {
+		static bool attr_set = false;
+		if (p.log2n == 10) {
+			/* N = 1024 with 16-bit bin indices (more than 256 bins): the general kernel at 128 threads per spectrum */
+			constexpr int N = 1024;
+			constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;
+			const int blocks = tiles < 4096 ? tiles : 4096;
+			if (p.fft_out)
+				hipLaunchKernelGGL((k1big_fft_bin<10, true>), dim3(blocks), dim3(N / 8), lds, s, p);
+			else
+				hipLaunchKernelGGL((k1big_fft_bin<10, false>), dim3(blocks), dim3(N / 8), lds, s, p);
+			return hipGetLastError();
+		}
 		if (p.log2n != 13)
 			return hipErrorInvalidValue;
 		constexpr int N = 8192;
 		constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;	/* exchange slab + twiddle table + window: 160 KiB */
 		int blocks = tiles < 256 ? tiles : 256;		/* one work-group (16 waves, 128 VGPRs) per CU */
-		static bool attr_set = false;
 		if (!attr_set) {
 			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
 			                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1385,6 +1747,23 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			hipLaunchKernelGGL(k1v2_fft_bin<true>, dim3(blocks), dim3(128), 0, s, p);
 		else
 			hipLaunchKernelGGL(k1v2_fft_bin<false>, dim3(blocks), dim3(128), 0, s, p);
+		return hipGetLastError();
+	}
+	if (p.variant == 5 || p.variant == 6) {
+		int blocks = (tiles + 3) / 4;
+		if (blocks > kK1MaxBlocks)
+			blocks = kK1MaxBlocks;
+		if (p.variant == 5) {
+			if (p.fft_out)
+				hipLaunchKernelGGL((k1d_fft_bin<true, 2>), dim3(blocks), dim3(256), 0, s, p);
+			else
+				hipLaunchKernelGGL((k1d_fft_bin<false, 2>), dim3(blocks), dim3(256), 0, s, p);
+		} else {
+			if (p.fft_out)
+				hipLaunchKernelGGL((k1d_fft_bin<true, 1>), dim3(blocks), dim3(256), 0, s, p);
+			else
+				hipLaunchKernelGGL((k1d_fft_bin<false, 1>), dim3(blocks), dim3(256), 0, s, p);
+		}
 		return hipGetLastError();
 	}
 	int blocks = (tiles + 3) / 4;
@@ -1846,6 +2225,244 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 		hipLaunchKernelGGL(k3_merge<1>, dim3(blocks), dim3(256), 0, s, p);
 	else
 		hipLaunchKernelGGL(k3_merge<2>, dim3(blocks), dim3(256), 0, s, p);
+	return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------ */
+/* K23: counts + state update per 4-column strip                             */
+/* ------------------------------------------------------------------------ */
+
+/* The state update of a cell needs the cell's count of EVERY batch, in order (display.cl:217-254 is not
+ * composable across batches), and a count needs all spectra of a batch -- which K1 spreads over the chip.
+ * K2/K3 therefore handed 16-bit counts through memory: 0.5 B per sample written and read again, 9 % of
+ * what the pipeline moves.  Here the work-group that owns a cell also counts it: 256 work-groups of 4
+ * columns, each walking the launch's batches in order.
+ *   counting   thread (r, c) = (tid >> 2, tid & 3) reads the dword of quad-row r, column c: 16 B per
+ *              quad-row and work-group; the 8 work-groups that share a 128-byte line are placed on the same
+ *              XCD (work-group b runs on XCD b % 8), so the line is fetched from HBM once and served from
+ *              that XCD's L2 to the others.  ds_add on cnt[bin][4]; lanes of one column that meet in a bin
+ *              are serialised by the LDS, which is the price of a pure tone only.
+ *   update     the thread that owns a cell reads and clears its counter: no zeroing pass; hist values stay in
+ *              registers for the whole launch (4 per thread at 256 bins); (d, e) per count from the host's
+ *              table in LDS (host powf = the oracle's binding).
+ *   columns    live sum = tile partials x weights in a fixed order (deterministic floats), live EMA and
+ *              max-hold with decay (display.cl:186-214,257-310) by one thread per column.
+ * 31 VGPRs, <= 20 KiB LDS: one such work-group fits beside the K1 work-groups of a CU. */
+#ifndef K23_DEPTH
+#define K23_DEPTH 4			/* batches in flight per thread (6 registers each) */
+#endif
+template <int CPT>		/* cells per thread: n_bins * 4 / 256, rounded up (4 at 256 bins) */
+__global__ __launch_bounds__(256)
+void k23_strip(const K23Params p)
+{
+	extern __shared__ uint32_t cnt_all[];			/* 2 x [n_bins][4]: batches alternate between them */
+	__shared__ float2 rise_lds[1025];
+	__shared__ float red_s[2][4][4], red_m[2][4][4];	/* [batch parity][wave][column] */
+
+	/* These four waves sit beside K1's eight on the CU and the batches of a launch are a serial chain through
+	 * them (~100 instructions per batch and wave): they go first whenever they have something to issue. */
+	__builtin_amdgcn_s_setprio(3);
+
+	const int tid = threadIdx.x;
+	const int r = tid >> 2, c = tid & 3;
+	const int wv = tid >> 6;
+	/* strips of one 128-byte line (32 columns) share an XCD: b = 8 i + x -> strip = (strips / 8) x + i */
+	const int strips = p.n >> 2;
+	const int b = blockIdx.x;
+	const int strip = (strips >= 8 && (strips & 7) == 0) ? (strips >> 3) * (b & 7) + (b >> 3) : b;
+	const int x0 = strip * 4;
+	const int ncell = p.n_bins * 4;
+	const int qrows = p.batch >> 2;				/* quad-rows per batch */
+	const int tiles = p.batch / p.tile;
+	const uint32_t n = (uint32_t)p.n;
+
+	for (int i = tid; i <= p.batch && i < 1025; i += 256)
+		rise_lds[i] = p.rise[i];
+	for (int i = tid; i < 2 * ncell; i += 256)
+		cnt_all[i] = 0;
+
+	/* this thread's cells: cell = tid + 256 j -> (bin, col) = (cell >> 2, cell & 3); offset of cell j in a
+	 * [bin][N] array = cell0 + 64 N j */
+	const uint32_t cell0 = (uint32_t)(tid >> 2) * n + x0 + c;
+	float hv[CPT];
+#pragma unroll
+	for (int j = 0; j < CPT; j++)
+		hv[j] = (tid + 256 * j < ncell) ? p.hist[cell0 + 64 * n * j] : 0.0f;
+	/* column state (threads 0..3) */
+	const int half = p.n >> 1;
+	float live = 0.0f, mh = 0.0f;
+	if (tid < 4) {
+		const int xi = (x0 + c) ^ half;			/* fft-shifted vertex index, display.cl:200-201 */
+		live = p.spectrum[xi].y;
+		mh   = p.spectrum[p.n + xi].y;
+	}
+	__syncthreads();
+
+	/* This thread's share of a batch: the dwords of quad-rows r, r + 64, r + 128, r + 192 (those below
+	 * qrows) in column c, and the partial of tile r.  Shares are requested K23_DEPTH - 1 batches ahead into a
+	 * ring of register sets, because under load a request takes ~3 us to come back and the batches are a serial
+	 * chain: with one batch of look-ahead the chain ran at 2.3 us per batch.  As in k1d_fft_bin the requests
+	 * are inline-asm loads and the waits hand-counted: every thread issues exactly 5 requests per batch (clamped,
+	 * never skipped), so "at most 5 (K23_DEPTH - 1) outstanding" means "this batch has landed".
+	 * The counters alternate between two arrays, so one barrier per batch is enough (a counter is cleared by its
+	 * owner two barriers before it is counted into again). */
+	uint32_t voff[4];
+	bool     vok[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		vok[u]  = (r + 64 * u) < qrows;
+		voff[u] = ((uint32_t)(vok[u] ? r + 64 * u : 0) * n + x0 + c) * 4;		/* bytes */
+	}
+	const bool pok = r < tiles;
+	const uint32_t poff = ((uint32_t)(pok ? r : 0) * n + x0 + c) * 8;		/* bytes */
+	const float pw = __builtin_amdgcn_exp2f(p.log2_w * (float)(p.batch - (r + 1) * p.tile));	/* (1-a)^(B-1-t_last) */
+
+	struct Share { uint32_t v[4]; v2f pv; };
+	Share ring[K23_DEPTH];
+	auto request = [&](Share &sh, int fb) {
+		const int fc = fb < p.n_batches ? fb : p.n_batches - 1;
+		const uint32_t *s1 = p.bins + (size_t)fc * qrows * n;			/* uniform bases, 32-bit lane offsets */
+		const float2 *p1 = p.partial + (size_t)fc * tiles * n;
+		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[0]) : "v"(voff[0]), "s"(s1) : "memory");
+		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[1]) : "v"(voff[1]), "s"(s1) : "memory");
+		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[2]) : "v"(voff[2]), "s"(s1) : "memory");
+		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[3]) : "v"(voff[3]), "s"(s1) : "memory");
+		asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sh.pv) : "v"(poff), "s"(p1) : "memory");
+	};
+	auto landed = [&](Share &sh) {
+		asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (K23_DEPTH - 1)) : "memory");
+		asm volatile("" : "+v"(sh.v[0]), "+v"(sh.v[1]), "+v"(sh.v[2]), "+v"(sh.v[3]), "+v"(sh.pv) :: "memory");
+	};
+
+	auto step = [&](Share &sh, int f) {
+		uint32_t *cnt = cnt_all + (f & 1) * ncell;
+		uint32_t *cntc = cnt + c;
+		landed(sh);
+		uint32_t vcur[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+			vcur[u] = sh.v[u];
+		const float px = sh.pv.x, py = sh.pv.y;
+		request(sh, f + K23_DEPTH);		/* this set is free again */
+		/* ---- count (display.cl:161-177) ---------------------------------- */
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			if (vok[u]) {
+				atomicAdd(&cntc[((vcur[u]      ) & 0xff) * 4], 1u);
+				atomicAdd(&cntc[((vcur[u] >>  8) & 0xff) * 4], 1u);
+				atomicAdd(&cntc[((vcur[u] >> 16) & 0xff) * 4], 1u);
+				atomicAdd(&cntc[((vcur[u] >> 24)       ) * 4], 1u);
+			}
+		}
+		/* ---- live sum / max of the batch from the tile partials (display.cl:139,149-150): the 16 tiles of a
+		 * wave's lanes with the same column by a fixed butterfly (deterministic), the 4 waves below */
+		{
+			float sv = 0.0f, m = -1000.0f;
+			if (pok) {
+				sv = px * pw;
+				m = py;
+			}
+			if (tiles > 64) {			/* tiles shorter than 16 spectra: the rest, in place */
+				const float2 *pp = p.partial + (size_t)f * tiles * n + x0 + c;
+				for (int j = r + 64; j < tiles; j += 64) {
+					const float2 v = pp[(uint32_t)j * n];
+					const int t_last = (j + 1) * p.tile - 1;
+					sv += v.x * __builtin_amdgcn_exp2f(p.log2_w * (float)(p.batch - 1 - t_last));
+					m = (m < v.y) ? v.y : m;
+				}
+			}
+#pragma unroll
+			for (int d = 4; d < 64; d <<= 1) {
+				const float so = __shfl_xor(sv, d, 64);
+				const float mo = __shfl_xor(m, d, 64);
+				sv += so;
+				m = (m < mo) ? mo : m;
+			}
+			if ((tid & 63) < 4) {
+				red_s[f & 1][wv][c] = sv;
+				red_m[f & 1][wv][c] = m;
+			}
+		}
+		__syncthreads();
+
+		/* ---- rise / decay of this thread's cells (display.cl:217-254), branch-free ---- */
+		uint32_t hc[CPT];
+#pragma unroll
+		for (int j = 0; j < CPT; j++)
+			hc[j] = (tid + 256 * j < ncell) ? cnt[tid + 256 * j] : 0;
+#pragma unroll
+		for (int j = 0; j < CPT; j++)
+			if (tid + 256 * j < ncell)
+				cnt[tid + 256 * j] = 0;
+#pragma unroll
+		for (int j = 0; j < CPT; j++) {
+			const float2 de = rise_lds[hc[j]];
+			float h = (hv[j] - de.x) * de.y + de.x;			/* display.cl:247 */
+			h = (h < 0.0f) ? 0.0f : h;				/* clamp, display.cl:250 */
+			h = (1.0f < h) ? 1.0f : h;
+			hv[j] = ((hv[j] <= 0.01f) && (hc[j] == 0)) ? hv[j] : h;	/* display.cl:237-238 */
+		}
+		if (f == p.n_batches - 1) {
+#pragma unroll
+			for (int j = 0; j < CPT; j++)
+				if (tid + 256 * j < ncell)
+					p.hc_export[cell0 + 64 * n * j] = hc[j];
+		}
+		/* ---- live EMA (display.cl:186-214), max-hold with decay (display.cl:257-310) */
+		if (tid < 4) {
+			float sum = red_s[f & 1][0][c], mx = red_m[f & 1][0][c];
+#pragma unroll
+			for (int w = 1; w < 4; w++) {				/* fixed order */
+				sum += red_s[f & 1][w][c];
+				mx = (mx < red_m[f & 1][w][c]) ? red_m[f & 1][w][c] : mx;
+			}
+			if (!__builtin_isfinite(live))
+				live = sum / 16.0f;			/* display.cl:206-207 */
+			live = live * p.live_decay + sum * p.alpha;	/* display.cl:210-211 */
+			if (!__builtin_isfinite(mh))
+				mh = -3.402823466e+38f;			/* display.cl:290-291 */
+			mh = mh * 0.999f + 0.001f * live;		/* display.cl:303 */
+			mh = (mh < mx) ? mx : mh;			/* display.cl:304-305 */
+		}
+	};
+
+	/* the state loads above are the compiler's own: used (waited for) here, not at their first use inside
+	 * the loop, where the compiler's vmcnt(0) would drain the request ring once per trip */
+#pragma unroll
+	for (int j = 0; j < CPT; j++)
+		asm volatile("" :: "v"(hv[j]));
+	asm volatile("" :: "v"(live), "v"(mh));
+#pragma unroll
+	for (int d = 0; d < K23_DEPTH; d++)
+		request(ring[d], d);
+#pragma unroll 1
+	for (int f0 = 0; f0 < p.n_batches; f0 += K23_DEPTH) {
+#pragma unroll
+		for (int d = 0; d < K23_DEPTH; d++)
+			if (f0 + d < p.n_batches)		/* uniform */
+				step(ring[d], f0 + d);
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* the look-ahead requests past the last batch */
+
+#pragma unroll
+	for (int j = 0; j < CPT; j++)
+		if (tid + 256 * j < ncell)
+			p.hist[cell0 + 64 * n * j] = hv[j];
+	if (tid < 4) {
+		const int xi = (x0 + c) ^ half;
+		const float vx = ((float)xi / (float)half) - 1.0f;	/* display.cl:209,293 */
+		p.spectrum[xi]       = make_float2(vx, live);
+		p.spectrum[p.n + xi] = make_float2(vx, mh);
+	}
+}
+
+hipError_t launch_k23(const K23Params &p, hipStream_t s)
+{
+	const size_t lds = (size_t)2 * p.n_bins * 4 * sizeof(uint32_t);
+	if (p.n_bins <= 256)
+		hipLaunchKernelGGL(k23_strip<4>, dim3(p.n / 4), dim3(256), lds, s, p);
+	else
+		hipLaunchKernelGGL(k23_strip<8>, dim3(p.n / 4), dim3(256), lds, s, p);
 	return hipGetLastError();
 }
 

@@ -82,7 +82,9 @@ int fosphor_amd_finish(struct fosphor *self);
  *   spectrum   float[2][N][2]      live then max-hold; (x, y) vertices,
  *                                  index = bin ^ N/2 (fft-shifted)
  *   hitcount   uint32[n_bins][N]   integer counts of the LAST batch processed
- * Pointers are device pointers, valid until fosphor_release. */
+ * Pointers are device pointers.  histogram / spectrum / hitcount stay where they are until fosphor_release;
+ * d_waterfall is one of two rings and must be re-queried after every process call (a call that rewrites
+ * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering). */
 struct fosphor_amd_buffers
 {
 	float    *d_waterfall;
@@ -146,6 +148,9 @@ int fosphor_amd_merge(struct fosphor *self, int total_batch);
  * milliseconds and launch counts per kernel since the last call, and resets. */
 void fosphor_amd_profile(struct fosphor *self, int enable);
 int  fosphor_amd_kernel_times(struct fosphor *self, float ms[3], int launches[3]);
+/* Milliseconds during which at least one K1 / K2 / K3 was running (union of the same intervals; K1s of
+ * consecutive sub-launches overlap on two streams).  Call before fosphor_amd_kernel_times, which resets. */
+int  fosphor_amd_kernel_busy(struct fosphor *self, float busy_ms[3]);
 
 /* The memory traffic of one K1 launch over (d_samples, n_batches, batch) -- its loads in its order
  * with its prefetch depth, its stores -- without the arithmetic: the practical floor the memory
@@ -172,6 +177,20 @@ int fosphor_amd_host_twiddles(float *out);
  * of launch i run on a second stream next to K1 of launch i+1.  0 = strictly one stream.
  * Results are identical; used by the bench to time K1 in isolation. */
 int fosphor_amd_set_overlap(struct fosphor *self, int enable);
+
+/* Ordering of fosphor_amd_process_device* calls against `stream` (the stream of the config, or the private one).
+ * A call with more samples than one sub-launch (64 Mi by default) is cut into sub-launches whose K1s alternate
+ * between `stream` and a second private stream, so that consecutive K1s overlap at their edges.
+ * strict = 1 (default): the call still behaves like work queued on `stream` -- its K1s start after what the
+ * caller queued there before the call, and what the caller queues there afterwards starts after them.
+ * strict = 0: no ordering against `stream` in either direction: the caller guarantees that the samples are
+ * complete before the call and keeps them intact until fosphor_amd_finish() or until work it queues behind
+ * fosphor_amd_wait_input(); consecutive CALLS then overlap at their edges as well.  Results are identical. */
+int fosphor_amd_set_input_ordering(struct fosphor *self, int strict);
+
+/* Makes `stream` wait (device-side, the host does not block) for every K1 queued so far, i.e. for the readers of
+ * all sample buffers handed to fosphor_amd_process_device* up to now.  0 / -EINVAL / -EIO. */
+int fosphor_amd_wait_input(struct fosphor *self);
 
 /* hipStream_t the instance runs on (K1), and the one K2 / K3 run on (a second stream while the
  * pipeline is on).  The all-reduce between accumulate and merge must be ordered on the latter. */

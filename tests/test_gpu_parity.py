@@ -269,20 +269,31 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
     f.close(); f2.close()
 
 
-@pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"}])
+@pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"},
+                                 {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K23": "1"},
+                                 {"FOSPHOR_AMD_ALT": "0"}, {"FOSPHOR_AMD_TILE": "16"}, {"FOSPHOR_AMD_SUB_LOG2": "17"},
+                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"}])
 def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
-    """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode and the
-    two-waves-per-spectrum K1 are scheduling choices: several back-to-back launches, then a switch to
-    the sharded path and back, must leave exactly the state of the sequential reference calls."""
+    """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the K1 variants
+    (two waves per spectrum; asm-prefetched, one or two spectra ahead), the fused count+merge kernel, the tile
+    length, sub-launches of one batch on alternating FFT streams (with and without stream ordering against the
+    caller) are scheduling choices: several back-to-back launches, then a switch to the sharded path and back,
+    must leave exactly the state of the sequential reference calls."""
     torch = torch_cuda
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        if not k.startswith("_"):
+            monkeypatch.setenv(k, v)
     nbat, b, launches = 4, 128, 4
     f = amd.Fosphor(max_spectra=nbat * b)
+    if env.get("_relaxed"):
+        assert f.set_input_ordering(False) == 0
+    keep = []			# relaxed ordering: the caller keeps the sample buffers until finish()
     o = Oracle()
     for L in range(launches):
         x = add_tone(gaussian_iq(nbat * b * 1024, 300 + L), 0.2, 0.05 * (L + 1))
-        assert f.process_device(torch.from_numpy(x).cuda(), nbat, b) == 0		# not synchronised in between
+        keep.append(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        assert f.process_device(keep[-1], nbat, b) == 0		# not synchronised in between
         for k in range(nbat):
             assert o.process(x[k * b * 1024:(k + 1) * b * 1024], nthreads=8) == 0
     compare_state(f, o, "4 launches of 4 x 128 (%s)" % env)
