@@ -120,6 +120,18 @@ def main(argv):
         meta[name] = m
         print("%-22s %d call(s)  %.1fs" % (name, len(res), time.time() - t0), flush=True)
 
+    if not argv or "glibc" in argv:
+        # The same reference kernels with the math built-ins bound to glibc's sinf/cosf/hypotf/log10f/roundf
+        # ("what a typical CPU OpenCL runtime would do") instead of the pinned portable header: the hit counts
+        # of every call, for an INFORMATIONAL comparison with a stated cell budget (the built-ins are
+        # implementation-defined in OpenCL, so neither binding is "the" reference).
+        arrays = {}
+        for name in ("c1_gauss_b16", "c2_tone_b32x3", "c5_wrap_b512_b1024", "c6_range_m20_5"):
+            for k, c in enumerate(run_case(name, gc.CASES[name], portable=False)):
+                arrays["%s_c%d_hc" % (name, k)] = hitcount_from_rows(c["wf_rows"], c["hs"], c["ho"], 128).astype(np.uint16)
+        np.savez_compressed(os.path.join(OUT, "glibc_binding_hc.npz"), **arrays)
+        meta["glibc_binding_hc"] = {k: sha(v) for k, v in arrays.items()}
+
     if not argv or "fft512" in argv:
         x = gc.fft512_input()
         y = RefKernels.fft(x, gc.hann512(), n=512)
@@ -179,4 +191,4 @@ def main(argv):
 
 
 if __name__ == "__main__":
-    main([a for a in sys.argv[1:] if a in gc.CASES or a in ("fft512", "cmap", "axis", "geom")])
+    main([a for a in sys.argv[1:] if a in gc.CASES or a in ("fft512", "cmap", "axis", "geom", "glibc")])
