@@ -13,13 +13,13 @@ CSRC    := gr-fosphor_amd/csrc
 LIB     := gr-fosphor_amd/libfosphor_amd.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -std=c++17 -fPIC -pthread -Wall -Wno-unused-function
 
-SRCS := $(CSRC)/fosphor_kernels.hip $(CSRC)/fosphor_cmap.hip $(CSRC)/fosphor_api.cpp $(CSRC)/fosphor_render.cpp $(CSRC)/fosphor_sink.cpp
+SRCS := $(CSRC)/fosphor_kernels.hip $(CSRC)/fosphor_cmap.hip $(CSRC)/fosphor_api.cpp $(CSRC)/fosphor_render.cpp $(CSRC)/fosphor_sink.cpp $(CSRC)/fosphor_exchange.cpp
 HDRS := $(CSRC)/fosphor_internal.h include/fosphor.h include/fosphor_amd.h include/fosphor_amd_sink.h include/fosphor_amd_cmap.h include/fosphor_amd_axis.h include/fosphor_portable_math.h
 
 all: $(LIB)
 
 $(LIB): $(SRCS) $(HDRS) Makefile
-	$(HIPCC) $(HIPFLAGS) -x hip -shared -o $@ $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -x hip -shared -o $@ $(SRCS) -ldl
 
 oracle:
 	$(MAKE) -C oracle all

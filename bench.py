@@ -122,7 +122,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1 or os.environ.get("FOSPHOR_AMD_FORCE_EXCHANGE"):
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -166,6 +166,8 @@ def main():
     else:
         sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw)
         f = sf.f
+        if not args.strict_ordering:
+            f.set_input_ordering(False)
 
     state = {"pos": 0}
 
@@ -306,9 +308,12 @@ def main():
                 "waterfall": "dead-store rule: a row that a later spectrum of the same call overwrites is not stored, "
                              "so a step stores the rows of its last %d of %d spectra (the ring ends in the same state; "
                              "the reference would store all of them)" % (min(wf_rows, F * spb), F * spb),
-                "input_ordering": "strict" if (args.strict_ordering or mode != "batch") else "relaxed",
+                "input_ordering": "strict" if args.strict_ordering else "relaxed",
                 "host_submit_fraction": t_submit / elapsed,
-                "exchange": "none" if world == 1 else "RCCL all-reduce of hit counts / live sum / max once per frame of %d batches per GPU" % F,
+                "exchange": "none" if (sf is None or not sf.active) else
+                            "native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
+                            "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else
+                                                              "one ncclGroup of three all-reduces", F),
             },
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

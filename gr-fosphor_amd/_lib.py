@@ -87,6 +87,13 @@ SIGNATURES = {
     "fosphor_amd_set_partial_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_get_partials": (C.c_int, [C.c_void_p, C.POINTER(Partials)]),
     "fosphor_amd_merge": (C.c_int, [C.c_void_p, C.c_int]),
+    "fosphor_amd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "fosphor_amd_comm_destroy": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "fosphor_amd_exchange_sliced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "fosphor_amd_merge_sliced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "fosphor_amd_gather_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fosphor_amd_profile": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3), C.POINTER(C.c_int * 3)]),
     "fosphor_amd_kernel_busy": (C.c_int, [C.c_void_p, C.POINTER(C.c_float * 3)]),

@@ -102,6 +102,19 @@ class Fosphor:
         self.L.fosphor_amd_get_partials(self.h, C.byref(p))
         return p
 
+    # ---- native exchange (RCCL, include/fosphor_amd.h) ------------------------
+    def exchange(self, comm):
+        return self.L.fosphor_amd_exchange(self.h, comm)
+
+    def exchange_sliced(self, comm, world, rank):
+        return self.L.fosphor_amd_exchange_sliced(self.h, comm, world, rank)
+
+    def merge_sliced(self, total_batch, world, rank):
+        return self.L.fosphor_amd_merge_sliced(self.h, total_batch, world, rank)
+
+    def gather_state(self, comm, world, rank):
+        return self.L.fosphor_amd_gather_state(self.h, comm, world, rank)
+
     def buffers(self):
         b = _lib.Buffers()
         self.L.fosphor_amd_get_buffers(self.h, C.byref(b))

@@ -721,7 +721,8 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 	return 1;
 }
 
-static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0, int hset = 0)
+static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, hipStream_t st, int use16 = 0, int hset = 0,
+                     int cell_begin = 0, int cell_end = 0)
 {
 	K3Params k3;
 	const size_t cells = (size_t)self->n_bins * self->n;
@@ -741,6 +742,7 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
 	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins; k3.n = self->n;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
+	k3.cell_begin = cell_begin; k3.cell_end = cell_end;
 	prof_begin(self, 2, st);
 	HIP_TRY(launch_k3(k3, st), "launch merge");
 	prof_end(self, st);
@@ -1158,12 +1160,112 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	if (!self || !d_samples || n_local < 16 || (n_local & 15) || (t_offset & 15) ||
 	    t_offset < 0 || t_offset + n_local > total_batch || n_local > self->max_spectra)
 		return -EINVAL;
+	const int did_prep = self->win_dirty || self->thr_dirty || self->state == ST_BOOTING;
 	if (prepare(self))
 		return -EIO;
 
-	/* same two-stream pipeline as run(): K1 on `stream`, K2 (and later the caller's all-reduce
-	 * and fosphor_amd_merge's K3) on `stream2`, intermediates rotating between two sets */
 	st2 = self->overlap ? self->stream2 : self->stream;
+	{
+		/* A shard of several whole 1024-spectrum chunks runs like a device-resident call: sub-launches of
+		 * sub_samples samples, K1s alternating between two streams, K2 of piece j beside K1 of piece j + 1.
+		 * Each K2 leaves its chunks' packed 16-bit count slabs and float partials at the chunks' places;
+		 * one k2c_sum at the end adds all of them into the 32-bit slot that is exchanged. */
+		const int cpb = n_local / 1024;
+		const size_t cells = (size_t)self->n_bins * self->n;
+		const int chunked = (n_local % 1024) == 0 && cpb > 1 && cpb <= self->max_batches && self->max_batches >= 4 &&
+		                    !getenv("FOSPHOR_AMD_NO_SUM16");
+		long long per_chunk = 1024LL * self->n;
+		int sub_c = (int)(self->sub_samples / per_chunk);
+		if (sub_c < 1) sub_c = 1;
+		if (chunked && cpb > sub_c) {
+			const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
+			const int use_alt = self->overlap && self->alt;
+			int used_alt = 0;
+			if (drain_h_sets(self, st2))
+				return -EIO;
+			if (use_alt && (did_prep || !self->relaxed)) {
+				HIP_TRY(hipEventRecord(self->ev_in, self->stream), "record input ready");
+				HIP_TRY(hipStreamWaitEvent(self->stream_alt, self->ev_in, 0), "second FFT stream waits for the input");
+			}
+			for (int c0 = 0; c0 < cpb; c0 += sub_c) {
+				const int nc = (cpb - c0 < sub_c) ? cpb - c0 : sub_c;
+				const int t0 = c0 * 1024, sub_total = nc * 1024;
+				hipStream_t ks = self->stream;
+				K2Params k2;
+				int stores_rows;
+
+				if (use_alt && (self->k1_seq++ & 1)) {
+					ks = self->stream_alt;
+					used_alt = 1;
+				}
+				set = self->pp;
+				self->pp = (self->pp + 1) % kSets;
+				self->d_bins = self->d_bins_pp[set];
+				self->d_partial = self->d_partial_pp[set];
+				if (self->overlap && self->set_used[set])
+					HIP_TRY(hipStreamWaitEvent(ks, self->ev_set_free[set], 0), "wait for intermediate set");
+				tile = pick_tile(self, sub_total, 1024);
+				/* global spectrum index tau = t_offset + t0 + t stores its row iff tau >= total_batch - wf_rows */
+				wf_first = total_batch - self->wf_rows - t_offset - t0;
+				if (wf_first < 0) wf_first = 0;
+				stores_rows = wf_first < sub_total;
+				if (!stores_rows) wf_first = sub_total;
+				fill_k1(self, &k1, (const char *)d_samples + (size_t)t0 * self->n * sample_bytes, sub_total, tile,
+				        (self->wf_pos + t_offset + t0) & (self->wf_rows - 1), wf_first);
+				if (stores_rows && wf_enter(self, ks))
+					return -EIO;
+				prof_begin(self, 0, ks);
+				HIP_TRY(launch_k1(k1, ks), "launch fft_bin");
+				prof_end(self, ks);
+				if (stores_rows && wf_leave(self, ks))
+					return -EIO;
+				if (self->overlap) {
+					HIP_TRY(hipEventRecord(self->ev_k1_done[set], ks), "record K1 done");
+					HIP_TRY(hipStreamWaitEvent(st2, self->ev_k1_done[set], 0), "K2 waits for K1");
+				}
+				memset(&k2, 0, sizeof(k2));
+				k2.bins = self->d_bins; k2.partial = self->d_partial;
+				k2.hc = self->d_hc + (size_t)self->slot * cells;
+				k2.hc16 = (uint16_t *)self->d_hc + ((size_t)self->max_batches + c0) * cells;
+				k2.n = self->n; k2.bins16 = self->bins16;
+				k2.batch = sub_total; k2.chunk = 1024; k2.tile = tile; k2.n_bins = self->n_bins;
+				k2.w = 1.0f - self->alpha;
+				k2.log2_w = (float)log2((double)(1.0f - self->alpha));
+				k2.t_offset = t_offset + t0; k2.weight_batch = total_batch;
+				k2.chunk_sum = self->d_chunk_sum + (size_t)c0 * self->n;
+				k2.chunk_max = self->d_chunk_max + (size_t)c0 * self->n;
+				prof_begin(self, 1, st2);
+				HIP_TRY(launch_k2(k2, nc, st2), "launch count");
+				prof_end(self, st2);
+				if (self->overlap) {
+					HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
+					self->set_used[set] = 1;
+				}
+			}
+			{
+				K2bParams k2b;
+				memset(&k2b, 0, sizeof(k2b));
+				k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
+				k2b.live_sum = self->d_live_sum + (size_t)self->slot * self->n;
+				k2b.vmax = self->d_vmax + (size_t)self->slot * self->n;
+				k2b.n_batches = 1; k2b.cpb = cpb; k2b.n = self->n;
+				k2b.hc16 = (uint16_t *)self->d_hc + (size_t)self->max_batches * cells;
+				k2b.hc = self->d_hc + (size_t)self->slot * cells;
+				k2b.n_bins = self->n_bins;
+				HIP_TRY(launch_k2c(k2b, st2), "launch chunk sum");
+			}
+			if (used_alt && !self->relaxed) {
+				HIP_TRY(hipEventRecord(self->ev_alt_done, self->stream_alt), "record second FFT stream");
+				HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_alt_done, 0), "stream waits for the second FFT stream");
+			}
+			self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
+			self->state = ST_PENDING;
+			return 0;
+		}
+	}
+
+	/* one K1 launch: same two-stream pipeline as run(): K1 on `stream`, K2 (and later the exchange and
+	 * fosphor_amd_merge's K3) on `stream2`, intermediates rotating between the sets */
 	set = self->pp;
 	self->pp = (self->pp + 1) % kSets;
 	self->d_bins = self->d_bins_pp[set];
@@ -1176,9 +1278,13 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	wf_first = total_batch - self->wf_rows - t_offset;
 	if (wf_first < 0) wf_first = 0;
 	fill_k1(self, &k1, d_samples, n_local, tile, (self->wf_pos + t_offset) & (self->wf_rows - 1), wf_first);
+	if (wf_enter(self, self->stream))
+		return -EIO;
 	prof_begin(self, 0, self->stream);
 	HIP_TRY(launch_k1(k1, self->stream), "launch fft_bin");
 	prof_end(self, self->stream);
+	if (wf_leave(self, self->stream))
+		return -EIO;
 
 	if (self->overlap) {
 		HIP_TRY(hipEventRecord(self->ev_k1_done[set], self->stream), "record K1 done");
@@ -1239,6 +1345,88 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 	self->last_hc16 = 0;
 	self->state = ST_PENDING;
 	return 0;
+}
+
+/* ---- native exchange (RCCL over xGMI), fosphor_exchange.cpp --------------- */
+
+extern "C" int fosphor_amd_comm_unique_id(void *id128)
+{
+	return id128 ? xchg_unique_id(id128) : -EINVAL;
+}
+
+extern "C" int fosphor_amd_comm_init(void **comm, int world, int rank, const void *id128)
+{
+	if (!comm || !id128 || world < 1 || rank < 0 || rank >= world)
+		return -EINVAL;
+	return xchg_comm_init(comm, world, rank, id128);
+}
+
+extern "C" int fosphor_amd_comm_destroy(void *comm)
+{
+	return comm ? xchg_comm_destroy(comm) : -EINVAL;
+}
+
+/* Between fosphor_amd_accumulate_device and fosphor_amd_merge: one ncclGroup of three all-reduces over the
+ * partial arrays of the current slot, queued on the count/merge stream (behind K2, in front of K3). */
+extern "C" int fosphor_amd_exchange(struct fosphor *self, void *comm)
+{
+	if (!self || !comm)
+		return -EINVAL;
+	const size_t cells = (size_t)self->n_bins * self->n;
+	return xchg_allreduce3(comm, self->overlap ? self->stream2 : self->stream,
+	                       self->d_hc + (size_t)self->slot * cells, cells,
+	                       self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
+	                       (size_t)self->n);
+}
+
+/* Frequency-sliced form for large states (128 MiB of counts at 65536 x 512): the counts are
+ * reduce-scattered -- rank r owns cells [r C / world, (r + 1) C / world) of the [bin][x] array -- and
+ * fosphor_amd_merge_sliced updates only that slice of the histogram; fosphor_amd_gather_state all-gathers the
+ * slices when a complete histogram is wanted on every rank (once per draw, not once per exchange). */
+extern "C" int fosphor_amd_exchange_sliced(struct fosphor *self, void *comm, int world, int rank)
+{
+	if (!self || !comm || world < 1 || rank < 0 || rank >= world)
+		return -EINVAL;
+	const size_t cells = (size_t)self->n_bins * self->n;
+	if (cells % (size_t)world)
+		return -EINVAL;
+	return xchg_reduce_scatter(comm, self->overlap ? self->stream2 : self->stream,
+	                           self->d_hc + (size_t)self->slot * cells, cells, world, rank,
+	                           self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
+	                           (size_t)self->n);
+}
+
+extern "C" int fosphor_amd_merge_sliced(struct fosphor *self, int total_batch, int world, int rank)
+{
+	if (!self || total_batch < 16 || world < 1 || rank < 0 || rank >= world)
+		return -EINVAL;
+	const size_t cells = (size_t)self->n_bins * self->n;
+	if (cells % (size_t)world)
+		return -EINVAL;
+	if (prepare(self))
+		return -EIO;
+	const int per = (int)(cells / (size_t)world);
+	if (run_merge(self, 1, total_batch, self->slot, self->overlap ? self->stream2 : self->stream, 0, 0,
+	              per * rank, per * (rank + 1)))
+		return -EIO;
+	self->last_batches = 1;
+	self->last_slot0 = self->slot;
+	self->last_hc16 = 0;
+	self->state = ST_PENDING;
+	return 0;
+}
+
+extern "C" int fosphor_amd_gather_state(struct fosphor *self, void *comm, int world, int rank)
+{
+	if (!self || !comm || world < 1 || rank < 0 || rank >= world)
+		return -EINVAL;
+	const size_t cells = (size_t)self->n_bins * self->n;
+	if (cells % (size_t)world)
+		return -EINVAL;
+	hipStream_t st = self->overlap ? self->stream2 : self->stream;
+	if (k3_stream_enter(self, st))
+		return -EIO;
+	return xchg_allgather_f32(comm, st, self->d_hist, cells, world, rank);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -106,6 +106,8 @@ struct K3Params {
 	int   n_batches, batch, n_bins, n;
 	float t0r, t0d, alpha;
 	float live_decay;		/* (1-alpha)^batch */
+	int   cell_begin, cell_end;	/* cells [begin, end) of the (bin, x) array are updated (0, 0 = all): the
+					 * frequency-sliced merge of the multi-GPU split; the columns always are */
 };
 
 /* K23: hit counts AND state update in one kernel (N = 1024 path, 8-bit bin indices, batch <= 1024).
@@ -134,6 +136,15 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
+
+/* fosphor_exchange.cpp: RCCL bound at run time */
+int xchg_unique_id(void *id128);
+int xchg_comm_init(void **comm, int world, int rank, const void *id128);
+int xchg_comm_destroy(void *comm);
+int xchg_allreduce3(void *comm, hipStream_t st, uint32_t *hc, size_t n_hc, float *sum, float *mx, size_t n_cols);
+int xchg_reduce_scatter(void *comm, hipStream_t st, uint32_t *hc, size_t n_hc, int world, int rank,
+                        float *sum, float *mx, size_t n_cols);
+int xchg_allgather_f32(void *comm, hipStream_t st, float *a, size_t n, int world, int rank);
 
 } // namespace fosphor_amd
 

@@ -2136,7 +2136,7 @@ void k3_merge(const K3Params p)
 	}
 	if (MODE == 0) {
 		/* cells handled above */
-	} else if (gid < cells) {
+	} else if (gid < cells && (p.cell_end == 0 || (gid >= p.cell_begin && gid < p.cell_end))) {
 		/* one (bin, x) cell; batches applied in order (display.cl:217-254).
 		 * d and e of display.cl:241-245 depend only on the hit count: with a table
 		 * rise[hc] = (d, e) (host-computed with the same powf the oracle uses) the update

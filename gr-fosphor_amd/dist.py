@@ -1,4 +1,4 @@
-"""Multi-GPU frame: one process per GPU, time-sharded batch, per-frame RCCL all-reduce.
+"""Multi-GPU frame: one process per GPU, time-sharded batch, one RCCL exchange per display frame.
 
 SURVEY 8e: the spectra of one batch are independent through FFT, log-power and binning; all
 cross-spectrum coupling is a commutative reduction per column --
@@ -7,10 +7,20 @@ cross-spectrum coupling is a commutative reduction per column --
     max         M[x]         float,  MAX
 after which every rank applies the identical merge kernel (K3) to identical inputs, so the
 persistent state is replicated bit-identically.  Waterfall rows stay with the rank that
-computed them.  torch.distributed ("nccl" = RCCL on ROCm) is the transport; the payload at
-1024 x 128 is 0.52 MiB, i.e. latency-bound on xGMI, so the three arrays go out as one
-coalesced group per frame.
+computed them.
+
+The exchange itself is native: `fosphor_amd_exchange` (gr-fosphor_amd/csrc/fosphor_exchange.cpp)
+issues ONE ncclGroup of three all-reduces on the library's count/merge stream, between K2 and K3,
+so a frame costs the host three C calls and the exchange of frame k overlaps K1 of frame k + 1.
+The communicator is the library's own (`NativeComm`); torch.distributed is only used to hand the
+128-byte RCCL id from rank 0 to the others.  For large states (65536 x 512: 128 MiB of counts) the
+frequency-sliced form reduce-scatters the counts and lets every rank merge only its slice.
+
+`allreduce_partials` / `combine_partials_numpy` are the same combination rule on torch / numpy
+arrays: the CPU tests (gloo, world size 2) and two-ranks-on-one-GPU tests use them as transport.
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -33,16 +43,12 @@ def wrap_device_array(ptr, shape, dtype):
 
 
 def allreduce_partials(hc, live_sum, vmax, group=None, async_op=False):
-    """The per-frame exchange.  Tensors are reduced in place; works on any backend
-    (RCCL on GPU tensors, gloo on CPU tensors in the tests).  hc must be an integer tensor
-    (uint32 counts viewed as int32: sums stay below 2^31 for any batch < 2^31 spectra).
-    async_op=True returns the work handles (wait() makes the current stream wait, not the host)."""
-    import os
+    """The combination rule through torch.distributed: three all-reduces, in place, on any backend (gloo on
+    CPU tensors in the tests).  hc must be an integer tensor (uint32 counts viewed as int32: sums stay below
+    2^31 for any batch < 2^31 spectra).  async_op=True returns the work handles."""
     import torch.distributed as dist
-    if not dist.is_initialized():
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return []
-    if dist.get_world_size(group) == 1 and not os.environ.get("FOSPHOR_AMD_FORCE_EXCHANGE"):
-        return []		# (the override runs the collectives on a single rank: a smoke test of the RCCL path)
     works = [
         dist.all_reduce(hc, op=dist.ReduceOp.SUM, group=group, async_op=True),
         dist.all_reduce(live_sum, op=dist.ReduceOp.SUM, group=group, async_op=True),
@@ -63,42 +69,100 @@ def shard_range(total_batch, rank, world):
     return rank * n, n
 
 
-class ShardedFosphor:
-    """One rank's half of a sharded fosphor instance.
+class NativeComm:
+    """The library's own RCCL communicator (fosphor_amd_comm_*).  `broadcast_id(id_bytes_or_None) -> bytes`
+    hands rank 0's 128-byte id to every rank; by default torch.distributed does it (any backend)."""
 
-    frame(d_samples_local, total_batch): K1+K2 on the local shard, all-reduce, K3.
+    def __init__(self, lib, rank, world, broadcast_id=None):
+        self.L, self.rank, self.world = lib, rank, world
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            rv = lib.fosphor_amd_comm_unique_id(buf)
+            if rv:
+                raise RuntimeError("fosphor_amd_comm_unique_id -> %d (is an RCCL library available?)" % rv)
+        ident = bytes(buf.raw)
+        if world > 1:
+            ident = (broadcast_id or self._torch_broadcast)(ident if rank == 0 else None)
+        self.h = C.c_void_p()
+        rv = lib.fosphor_amd_comm_init(C.byref(self.h), world, rank, ident)
+        if rv:
+            raise RuntimeError("fosphor_amd_comm_init -> %d" % rv)
+
+    @staticmethod
+    def _torch_broadcast(ident):
+        import torch.distributed as dist
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fosphor_amd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedFosphor:
+    """One rank's part of a sharded fosphor instance.
+
+    frame(d_samples_local, total_batch): K1 + K2 on the local time block, exchange, K3.
     The semantics are one reference display launch with fft_batch = total_batch (the kernel
     is batch-generic; only the host caps it, cl.c:885).
 
-    With overlap=True the exchange of frame k is left in flight while the caller submits
-    frame k+1 (two partial-array slots in the library); its merge is queued behind frame k+1's
-    FFT.  Call flush() to retire the last frame.
+    exchange = "rccl"   (default on GPUs) the native exchange on the library's count/merge stream: nothing
+                        waits on the host, frame k's exchange overlaps frame k+1's K1 by construction.
+               "torch"  the same three all-reduces through torch.distributed on views of the library's arrays
+                        (any backend; what the two-ranks-on-one-GPU gloo test uses).  With overlap=True the
+                        exchange of frame k is left in flight while frame k+1 is submitted (two slots).
+    sliced: reduce-scatter + frequency-sliced merge (rccl only); default for states of 16 MiB and more.
+    force_exchange: run the collectives on a single rank too (smoke test of the RCCL path).
     """
 
-    def __init__(self, fosphor_cls, rank, world, group=None, **kw):
+    def __init__(self, fosphor_cls, rank, world, group=None, exchange=None, sliced=None, force_exchange=False,
+                 comm=None, **kw):
+        import os
         import torch
         self.torch = torch
         self.rank, self.world, self.group = rank, world, group
-        # The library runs on a torch-owned, NON-default stream and every frame is submitted under
-        # it, so the collective (which torch orders after the current stream) follows K2, and K3
-        # follows the collective (work.wait() makes this stream wait) without host synchronisation.
-        # torch's default stream has handle 0, which the C ABI reads as "create a private stream":
-        # that would silently break the ordering, hence the explicit stream.
+        # K1 runs on a torch-owned, NON-default stream (torch's default stream has handle 0, which the C ABI
+        # reads as "create a private stream"), so that the caller's producer of the samples can be ordered
+        # in front of it with wait_stream.
         self.stream = torch.cuda.Stream()
         self.f = fosphor_cls(stream=self.stream.cuda_stream, **kw)
-        # K2 / all-reduce / K3 live on the library's second stream, so that they overlap the
-        # NEXT frame's K1 (VALU-bound) instead of queueing behind it
+        self.force = bool(force_exchange or os.environ.get("FOSPHOR_AMD_FORCE_EXCHANGE"))
+        if exchange is None:
+            exchange = os.environ.get("FOSPHOR_AMD_EXCHANGE", "rccl")
+        self.exchange = exchange
+        self.active = world > 1 or self.force
+        cells = self.f.n_bins * self.f.n
+        self.sliced = (cells * 4 >= (16 << 20)) if sliced is None else bool(sliced)
+        if cells % world:
+            self.sliced = False
+        self.comm = None
+        if self.active and exchange == "rccl":
+            self.comm = comm or NativeComm(self.f.L, rank, world)
+        else:
+            self.sliced = False
+        # "torch" transport: K2 / all-reduce / K3 live on the library's second stream
         self.stream_b = torch.cuda.ExternalStream(self.f.stream2)
         self.views = []
-        for slot in (0, 1):
-            self.f.set_partial_slot(slot)
-            p = self.f.partials()
-            self.views.append((wrap_device_array(p.d_hc, (p.n_hc,), torch.int32),
-                               wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32),
-                               wrap_device_array(p.d_max, (p.n_cols,), torch.float32)))
+        if self.active and exchange == "torch":
+            for slot in (0, 1):
+                self.f.set_partial_slot(slot)
+                p = self.f.partials()
+                self.views.append((wrap_device_array(p.d_hc, (p.n_hc,), torch.int32),
+                                   wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32),
+                                   wrap_device_array(p.d_max, (p.n_cols,), torch.float32)))
+        self.f.set_partial_slot(0)
         self.k = 0
-        self.pending = None		# (works, slot, total_batch)
+        self.pending = None		# torch transport: (works, slot, total_batch)
 
+    # ---- torch transport --------------------------------------------------------
     def _retire(self):
         if self.pending is None:
             return
@@ -116,25 +180,63 @@ class ShardedFosphor:
         record + wait between the caller's stream and the FFT stream, two queue packets per frame)."""
         torch = self.torch
         off, n = shard_range(total_batch, self.rank, self.world)
-        slot = self.k & 1
-        self.k += 1
         if wait_producer:
             self.stream.wait_stream(torch.cuda.current_stream())	# the caller's producer of d_samples_local
-        with torch.cuda.stream(self.stream):
-            self.f.set_partial_slot(slot)
-            rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)	# K1 here, K2 on stream_b
+        if self.exchange == "torch" and self.active:
+            slot = self.k & 1
+            self.k += 1
+            with torch.cuda.stream(self.stream):
+                self.f.set_partial_slot(slot)
+                rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)	# K1 here, K2 on stream_b
+                if rv:
+                    raise RuntimeError("accumulate_device -> %d" % rv)
+            with torch.cuda.stream(self.stream_b):
+                import torch.distributed as dist
+                h, s, m = self.views[slot]
+                works = [dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                         dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                         dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group, async_op=True)]
+                self._retire()			# previous frame: wait for ITS exchange, merge (K3 on stream_b)
+                self.pending = (works, slot, total_batch)
+                if not overlap:
+                    self._retire()
+            return
+        # native transport (or a single rank without exchange): three C calls, all asynchronous; K2, the
+        # exchange and K3 follow each other on the library's count/merge stream while `stream` is already free
+        # for the next frame's K1
+        rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)
+        if rv:
+            raise RuntimeError("accumulate_device -> %d" % rv)
+        if self.comm is not None:
+            if self.sliced:
+                rv = self.f.exchange_sliced(self.comm.h, self.world, self.rank)
+                rv = rv or self.f.merge_sliced(total_batch, self.world, self.rank)
+            else:
+                rv = self.f.exchange(self.comm.h)
+                rv = rv or self.f.merge(total_batch)
+        else:
+            rv = self.f.merge(total_batch)
+        if rv:
+            raise RuntimeError("exchange / merge -> %d" % rv)
+
+    def gather_state(self):
+        """Sliced mode: make the histogram complete on every rank (once per draw)."""
+        if self.sliced and self.comm is not None:
+            rv = self.f.gather_state(self.comm.h, self.world, self.rank)
             if rv:
-                raise RuntimeError("accumulate_device -> %d" % rv)
-        with torch.cuda.stream(self.stream_b):
-            works = allreduce_partials(*self.views[slot], group=self.group, async_op=True)
-            self._retire()			# previous frame: wait for ITS exchange, merge (K3 on stream_b)
-            self.pending = (works, slot, total_batch)
-            if not overlap:
-                self._retire()
+                raise RuntimeError("gather_state -> %d" % rv)
 
     def flush(self):
-        with self.torch.cuda.stream(self.stream_b):
-            self._retire()
+        if self.pending is not None:
+            with self.torch.cuda.stream(self.stream_b):
+                self._retire()
+
+    def close(self):
+        self.flush()
+        self.f.finish()
+        if self.comm is not None:
+            self.comm.close()
+        self.f.close()
 
 
 def combine_partials_numpy(parts):

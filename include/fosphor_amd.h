@@ -120,7 +120,7 @@ int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *
 int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
                                   int n_local, int t_offset, int total_batch);
 
-/* Select which of the instance's partial-array slots (0 .. max_batches-1) the next
+/* Select which of the instance's partial-array slots (0 .. max_batches/2 - 1) the next
  * accumulate / get_partials / merge use.  Two slots let the all-reduce of frame k overlap the
  * FFT of frame k+1. */
 int fosphor_amd_set_partial_slot(struct fosphor *self, int slot);
@@ -138,6 +138,34 @@ int fosphor_amd_get_partials(struct fosphor *self, struct fosphor_amd_partials *
 
 /* Apply K3 with the (reduced) partial arrays as one batch of total_batch spectra. */
 int fosphor_amd_merge(struct fosphor *self, int total_batch);
+
+/* ---- the exchange itself, native: RCCL over xGMI (bound at run time, so single-GPU users need no RCCL) ----
+ *
+ * One communicator per process / GPU.  Rank 0 obtains a 128-byte id and hands it to the other ranks by any
+ * means (MPI, a file, torch.distributed); every rank then calls fosphor_amd_comm_init with the same id.
+ * Per display frame a rank calls
+ *     fosphor_amd_accumulate_device(...)      K1 on `stream`, K2 on the count/merge stream
+ *     fosphor_amd_exchange(self, comm)        ncclGroupStart; AllReduce(hc, u32, sum); AllReduce(live sum, f32,
+ *                                             sum); AllReduce(max, f32, max); ncclGroupEnd -- same stream
+ *     fosphor_amd_merge(self, total_batch)    K3, same stream
+ * and none of the three waits on the host: the exchange of frame k overlaps K1 of frame k + 1.
+ * Integer sums are exact and order-independent, so the reduced counts are bit-identical on every rank and to a
+ * single-GPU launch with fft_batch = total_batch; every rank then applies the identical K3 to identical
+ * inputs (replicated state).  0 / -EINVAL / -EIO / -ENOSYS (no RCCL library found). */
+int fosphor_amd_comm_unique_id(void *id128);
+int fosphor_amd_comm_init(void **comm, int world, int rank, const void *id128);	/* on the current HIP device */
+int fosphor_amd_comm_destroy(void *comm);
+int fosphor_amd_exchange(struct fosphor *self, void *comm);
+
+/* Frequency-sliced form for large states (65536 x 512: 128 MiB of counts): the counts are reduce-scattered,
+ * rank r owning cells [r C / world, (r + 1) C / world) of the [bin][x] arrays (C = n_bins * N must divide), and
+ * fosphor_amd_merge_sliced updates only that slice of the histogram (live / max-hold columns: everywhere).
+ * Half the bytes of an all-reduce per exchange and 1 / world of the merge per rank.  The histogram is then
+ * complete on a rank only inside its slice until fosphor_amd_gather_state all-gathers it (once per draw, if a
+ * single-device view is wanted at all); the hitcount view is valid inside the slice only. */
+int fosphor_amd_exchange_sliced(struct fosphor *self, void *comm, int world, int rank);
+int fosphor_amd_merge_sliced(struct fosphor *self, int total_batch, int world, int rank);
+int fosphor_amd_gather_state(struct fosphor *self, void *comm, int world, int rank);
 
 /* ---- measurement ---------------------------------------------------------- */
 

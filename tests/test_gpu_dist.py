@@ -1,4 +1,5 @@
-"""GPU: two ranks of gr_fosphor_amd.dist.ShardedFosphor on ONE device over gloo.
+"""GPU: gr_fosphor_amd.dist.ShardedFosphor -- two ranks on ONE device over gloo, and the native RCCL exchange
+(fosphor_amd_exchange: one ncclGroup on the library's stream) on a single rank.
 
 The 8-GPU RCCL run is the driver's; this exercises the same rank code (time-sharded accumulate,
 per-frame all-reduce of hit counts / live sum / max with the previous frame's exchange left in
@@ -28,7 +29,7 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 N = 1024
 frames = [2048, 2048, 1024]		# spectra per frame (all ranks together)
-sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, max_spectra=2048)
+sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", max_spectra=2048)	# gloo carries the arrays
 o = Oracle()
 t0 = 0
 for k, total in enumerate(frames):
@@ -81,3 +82,59 @@ def test_two_rank_frames_on_one_gpu(tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
         assert "rank %d ok" % r in out
+
+
+NATIVE = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["FOSPHOR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FOSPHOR_ROOT"], "tests"))
+import torch
+from _pkg import gr_fosphor_amd
+from gr_fosphor_amd.dist import ShardedFosphor
+from oracle_lib import Oracle, gaussian_iq, add_tone
+
+# One rank, the library's OWN RCCL communicator (no torch.distributed at all): accumulate -> ncclGroup of three
+# all-reduces on the count/merge stream -> merge, several frames back to back without host synchronisation.
+torch.cuda.set_device(0)
+N = 1024
+sliced = os.environ.get("FOSPHOR_TEST_SLICED") == "1"
+frames = [2048, 1024, 4096, 2048]
+sf = ShardedFosphor(gr_fosphor_amd.Fosphor, 0, 1, exchange="rccl", force_exchange=True, sliced=sliced, max_spectra=4096)
+assert sf.comm is not None and sf.sliced == sliced
+o = Oracle()
+t0 = 0
+keep = []
+for k, total in enumerate(frames):
+    x = add_tone(gaussian_iq(total * N, 170 + k), 0.1, 0.09 + 0.02 * k, t0=t0)
+    t0 += total * N
+    keep.append(torch.from_numpy(x).cuda())
+    sf.frame(keep[-1], total)
+    assert o.process(x, strict=False, nthreads=4) == 0
+sf.gather_state()
+f = sf.f
+assert f.finish() >= 0
+assert f.waterfall_pos == o.waterfall_pos
+assert np.array_equal(f.hitcount, o.hitcount.T), "hit counts differ from the oracle"
+assert np.allclose(f.histogram, o.histogram, rtol=1e-4, atol=2e-6)
+assert np.allclose(f.spectrum[..., 1], o.spectrum[..., 1], rtol=1e-4, atol=1e-6)
+rows = (o.waterfall_pos - 1024 + np.arange(1024)) & 1023
+assert np.allclose(f.waterfall[rows], o.waterfall[rows], rtol=1e-4, atol=1e-6)
+sf.close()
+print("native ok")
+'''
+
+
+@pytest.mark.parametrize("sliced", ["0", "1"])
+def test_native_rccl_exchange_single_rank(tmp_path, sliced):
+    """fosphor_amd_exchange / fosphor_amd_exchange_sliced on a real RCCL communicator (world size 1: the
+    8-GPU run is the driver's): stream ordering K2 -> ncclGroup -> K3 without host waits, library-owned
+    buffers, reduce-scatter + sliced merge + all-gather; state equal to the oracle's after four frames."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    script = tmp_path / "native.py"
+    script.write_text(NATIVE)
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, FOSPHOR_TEST_SLICED=sliced)
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and "native ok" in p.stdout, p.stdout[-3000:]
