@@ -130,6 +130,8 @@ SIGNATURES = {
     "fosphor_amd_fifo_read_peek": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
     "fosphor_amd_fifo_read_discard": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_sink_new": (C.c_void_p, []),
+    "fosphor_amd_sink_new_len": (C.c_void_p, [C.c_int]),
+    "fosphor_amd_sink_feed": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_sink_free": (None, [C.c_void_p]),
     "fosphor_amd_sink_start": (C.c_int, [C.c_void_p]),
     "fosphor_amd_sink_stop": (C.c_int, [C.c_void_p]),

@@ -80,30 +80,105 @@ void fifo::read_discard(int size)					/* fifo.cc:90-98 */
 	d_cond_full.notify_one();
 }
 
+int fifo::peek_max_size_at(int offset)
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	const int avail = used() - offset;
+	const int to_end = d_len - ((d_rp + offset) & (d_len - 1));
+	if (avail <= 0)
+		return 0;
+	return avail < to_end ? avail : to_end;
+}
+
+std::complex<float> *fifo::peek_at(int offset)
+{
+	std::unique_lock<std::mutex> lock(d_mutex);
+	return &d_buf[(d_rp + offset) & (d_len - 1)];
+}
+
 /* ------------------------------------------------------------------------ */
 /* sink_runtime (lib/base_sink_c_impl.cc)                                   */
 /* ------------------------------------------------------------------------ */
 
 const int sink_runtime::k_db_per_div[5] = {1, 2, 5, 10, 20};		/* base_sink_c_impl.cc:48 */
 
-sink_runtime::sink_runtime()
+sink_runtime::sink_runtime(int fifo_length)
   : d_fosphor(nullptr), d_active(false), d_frozen(false), d_visible(true), d_draining(false),
     d_settings_changed(0), d_db_ref(0), d_db_per_div_idx(3),
     d_zoom_enabled(false), d_zoom_center(0.5), d_zoom_width(0.2), d_ratio(0.35f),
-    d_have_window(false), d_frames(0), d_samples(0)
+    d_have_window(false), d_frames(0), d_samples(0),
+    d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0),
+    d_copy_gen(0), d_copy_pending(0), d_copy_quit(false)
 {
 	d_frequency.center = 0.0;
 	d_frequency.span = 1.0;
-	d_fifo = new fifo(2 * 1024 * 1024, true);			/* base_sink_c_impl.cc:58 */
+	d_fifo = new fifo(fifo_length, true);				/* base_sink_c_impl.cc:58 */
 	d_render_main = new fosphor_render();
 	fosphor_render_defaults(d_render_main);				/* :61-62 */
+	for (int i = 0; i < kMaxInflight; i++)
+		d_events[i] = nullptr;
+	for (int i = 0; i < kCopyHelpers; i++) {
+		d_copy_jobs[i].gen = 0;
+		d_copy_threads[i] = std::thread(&sink_runtime::copy_helper, this, i);
+	}
 }
 
 sink_runtime::~sink_runtime()
 {
 	stop();
+	{
+		std::lock_guard<std::mutex> lock(d_copy_mutex);
+		d_copy_quit = true;
+	}
+	d_copy_cv.notify_all();
+	for (int i = 0; i < kCopyHelpers; i++)
+		d_copy_threads[i].join();
+	for (int i = 0; i < kMaxInflight; i++)
+		if (d_events[i])
+			(void)hipEventDestroy((hipEvent_t)d_events[i]);
 	delete d_render_main;
 	delete d_fifo;
+}
+
+void sink_runtime::copy_helper(int idx)
+{
+	int seen = 0;
+	for (;;) {
+		copy_job job;
+		{
+			std::unique_lock<std::mutex> lock(d_copy_mutex);
+			d_copy_cv.wait(lock, [&] { return d_copy_quit || d_copy_jobs[idx].gen != seen; });
+			if (d_copy_quit)
+				return;
+			job = d_copy_jobs[idx];
+			seen = job.gen;
+		}
+		memcpy(job.dst, job.src, sizeof(std::complex<float>) * job.n);
+		{
+			std::lock_guard<std::mutex> lock(d_copy_mutex);
+			d_copy_pending--;
+		}
+		d_copy_done_cv.notify_one();
+	}
+}
+
+/* Regions whose upload has completed go back to the producer, oldest first.  wait_all: after the frame's
+ * synchronisation point (or at shutdown) everything queued has completed. */
+void sink_runtime::retire_uploads(bool wait_all)
+{
+	while (d_inflight_n) {
+		hipEvent_t ev = (hipEvent_t)d_inflight[d_inflight_head].event;
+		if (ev) {
+			if (wait_all)
+				(void)hipEventSynchronize(ev);
+			else if (hipEventQuery(ev) != hipSuccess)
+				break;
+		}
+		d_fifo->read_discard(d_inflight[d_inflight_head].len);		/* :174 */
+		d_inflight_samples -= d_inflight[d_inflight_head].len;
+		d_inflight_head = (d_inflight_head + 1) % kMaxInflight;
+		d_inflight_n--;
+	}
 }
 
 void sink_runtime::settings_mark_changed(uint32_t s)			/* :204-209 */
@@ -145,8 +220,10 @@ void sink_runtime::worker()						/* :77-122 */
 		return;
 	}
 	settings_apply(~(uint32_t)SETTING_DIMENSIONS);			/* :106-109 */
-	while (d_active || (d_draining && d_fifo->used() >= 16 * 1024))
+	while (d_active || (d_draining && d_fifo->used() - d_inflight_samples >= 16 * 1024))
 		render();
+	(void)fosphor_amd_finish(d_fosphor);
+	retire_uploads(true);
 	fosphor_release(d_fosphor);
 	d_fosphor = nullptr;
 }
@@ -154,45 +231,63 @@ void sink_runtime::worker()						/* :77-122 */
 void sink_runtime::render()						/* :130-201 */
 {
 	const int fft_len = 1024, batch_mult = 16, batch_max = 1024, max_iter = 8;
-	int i, tot_len;
+	int i, queued = 0;
 
 	settings_apply(settings_get_and_reset_changed());
 
-	tot_len = d_fifo->used();
-	for (i = 0; i < max_iter && tot_len; i++) {
-		int len = tot_len;
-		if (len > d_fifo->read_max_size())
-			len = d_fifo->read_max_size();
+	retire_uploads(false);
+	for (i = 0; i < max_iter; i++) {
+		/* the next region starts behind the ones still in flight (they are not discarded yet) */
+		int len = d_fifo->peek_max_size_at(d_inflight_samples);
 		len &= ~((batch_mult * fft_len) - 1);			/* :156 */
 		if (len > (batch_max * fft_len))
 			len = batch_max * fft_len;			/* :157-158 */
-		tot_len -= len;
 		if (!len)
 			break;
+		if (d_inflight_n == kMaxInflight)
+			retire_uploads(true);
+		std::complex<float> *data = d_fifo->peek_at(d_inflight_samples);
+		const int slot = (d_inflight_head + d_inflight_n) % kMaxInflight;
+		void *ev = nullptr;
 		if (!d_frozen) {
-			std::complex<float> *data = d_fifo->read_peek(len, false);
 			int rv;
 			if (d_fifo->pinned()) {
-				/* DMA straight from the ring; the region is released only once the copy is done */
+				/* DMA straight from the ring; the region goes back to the producer once the event behind
+				 * its copy has completed -- nothing waits here, the next region's copy queues behind it */
 				rv = fosphor_amd_process_pinned(d_fosphor, data, len);
-				(void)fosphor_amd_wait_upload(d_fosphor);
+				if (!d_events[slot]) {
+					hipEvent_t e;
+					if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
+						d_events[slot] = e;
+				}
+				if (d_events[slot] && hipEventRecord((hipEvent_t)d_events[slot], (hipStream_t)fosphor_amd_stream(d_fosphor)) == hipSuccess)
+					ev = d_events[slot];
+				else
+					(void)fosphor_amd_wait_upload(d_fosphor);
 			} else {
-				rv = fosphor_process(d_fosphor, data, len);
+				rv = fosphor_process(d_fosphor, data, len);	/* copies before it returns */
 			}
 			if (rv == 0)
 				d_samples += (uint64_t)len;
 		}
-		d_fifo->read_discard(len);				/* :174 */
+		d_inflight[slot].event = ev;
+		d_inflight[slot].len = len;
+		d_inflight_n++;
+		d_inflight_samples += len;
+		queued++;
+		retire_uploads(false);
 	}
 
 	if (d_visible) {
 		fosphor_draw(d_fosphor, d_render_main);			/* :178-195: the per-frame sync point */
 		d_frames++;
+		retire_uploads(true);
 	} else {
 		std::this_thread::sleep_for(std::chrono::milliseconds(10));	/* :197-200 */
+		retire_uploads(false);
 	}
-	if (!tot_len && i == 0)
-		std::this_thread::sleep_for(std::chrono::microseconds(200));	/* nothing queued: do not spin */
+	if (!queued)
+		std::this_thread::sleep_for(std::chrono::microseconds(100));	/* nothing queued: do not spin */
 }
 
 int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432-462 */
@@ -206,7 +301,27 @@ int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432
 	std::complex<float> *dst = d_fifo->write_prepare(l, true);
 	if (!dst)
 		return 0;
-	memcpy(dst, in, sizeof(std::complex<float>) * (size_t)l);
+	if (l >= 128 * 1024) {
+		/* one core copies ~12 GB/s; the link behind the FIFO carries 4-5 times that */
+		const size_t part = ((size_t)l / (kCopyHelpers + 1)) & ~(size_t)1023;
+		{
+			std::lock_guard<std::mutex> lock(d_copy_mutex);
+			d_copy_gen++;
+			for (int k = 0; k < kCopyHelpers; k++) {
+				d_copy_jobs[k].dst = dst + part * (k + 1);
+				d_copy_jobs[k].src = in + part * (k + 1);
+				d_copy_jobs[k].n = (k == kCopyHelpers - 1) ? (size_t)l - part * kCopyHelpers : part;
+				d_copy_jobs[k].gen = d_copy_gen;
+			}
+			d_copy_pending = kCopyHelpers;
+		}
+		d_copy_cv.notify_all();
+		memcpy(dst, in, sizeof(std::complex<float>) * part);
+		std::unique_lock<std::mutex> lock(d_copy_mutex);
+		d_copy_done_cv.wait(lock, [&] { return d_copy_pending == 0; });
+	} else {
+		memcpy(dst, in, sizeof(std::complex<float>) * (size_t)l);
+	}
 	d_fifo->write_commit(l);
 	return l;
 }
@@ -285,7 +400,7 @@ using fosphor_amd::fifo;
 using fosphor_amd::sink_runtime;
 
 struct fosphor_amd_fifo { fifo f; fosphor_amd_fifo(int n, bool p) : f(n, p) {} };
-struct fosphor_amd_sink { sink_runtime s; };
+struct fosphor_amd_sink { sink_runtime s; explicit fosphor_amd_sink(int n) : s(n) {} };
 
 extern "C" {
 
@@ -305,7 +420,31 @@ int   fosphor_amd_fifo_read_max_size(fosphor_amd_fifo *f) { return f->f.read_max
 void *fosphor_amd_fifo_read_peek(fosphor_amd_fifo *f, int size, int wait) { return f->f.read_peek(size, wait != 0); }
 void  fosphor_amd_fifo_read_discard(fosphor_amd_fifo *f, int size) { f->f.read_discard(size); }
 
-fosphor_amd_sink *fosphor_amd_sink_new(void) { return new fosphor_amd_sink(); }
+fosphor_amd_sink *fosphor_amd_sink_new(void) { return new fosphor_amd_sink(2 * 1024 * 1024); }
+fosphor_amd_sink *fosphor_amd_sink_new_len(int fifo_length)
+{
+	if (fifo_length < 32 * 1024 || (fifo_length & (fifo_length - 1)))
+		return nullptr;
+	return new fosphor_amd_sink(fifo_length);
+}
+double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, int chunk, int repeats)
+{
+	const std::complex<float> *in = (const std::complex<float> *)samples;
+	const uint64_t before = s->s.samples_processed();
+	const uint64_t want = before + (uint64_t)n * (uint64_t)repeats;
+	auto t0 = std::chrono::steady_clock::now();
+	for (int r = 0; r < repeats; r++) {
+		int pos = 0;
+		while (pos < n) {
+			int l = n - pos < chunk ? n - pos : chunk;
+			int took = s->s.work(l, in + pos);
+			pos += took;
+		}
+	}
+	while (s->s.samples_processed() < want)
+		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 void  fosphor_amd_sink_free(fosphor_amd_sink *s) { delete s; }
 int   fosphor_amd_sink_start(fosphor_amd_sink *s) { return s->s.start() ? 1 : 0; }
 int   fosphor_amd_sink_stop(fosphor_amd_sink *s) { return s->s.stop() ? 1 : 0; }

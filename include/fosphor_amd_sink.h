@@ -10,9 +10,12 @@
  *
  * Differences from the reference, all on purpose:
  *   - the FIFO lives in pinned host memory and fosphor_amd_process_pinned() DMAs straight out of
- *     it; read_discard() happens only after the copy's event has completed.  The reference
- *     enqueues a non-blocking write from the FIFO and discards immediately
+ *     it; several regions are in flight at once and a region is read_discard()ed only when the event
+ *     behind ITS copy has completed (checked without blocking; the per-frame fosphor_draw is the only
+ *     wait).  The reference enqueues a non-blocking write from the FIFO and discards immediately
  *     (cl.c:903-910 vs base_sink_c_impl.cc:168-174): a latent race, not reproduced;
+ *   - work() splits copies of 128 Ki samples and more over a few helper threads (one core's memcpy is
+ *     ~1.5 GSamples/s, a PCIe Gen5 x16 link carries ~6.5);
  *   - no GL context: "visible" only decides whether render() synchronises (fosphor_draw) per frame;
  *   - set_fft_window takes the 1024 taps (gr::fft::window::build is GNU Radio's, the caller's).
  */
@@ -51,6 +54,11 @@ class fifo
 	int read_max_size();
 	std::complex<float> *read_peek(int size, bool wait = true);
 	void read_discard(int size);
+	/* regions beyond the read pointer (the sink keeps several uploads in flight before discarding):
+	 * contiguous samples available at `offset` behind the read pointer, and their address */
+	int peek_max_size_at(int offset);
+	std::complex<float> *peek_at(int offset);
+	int length() const { return d_len; }
 
 	bool pinned() const { return d_pinned; }
 
@@ -72,7 +80,7 @@ class sink_runtime
 		RATIO_UP, RATIO_DOWN, FREEZE_TOGGLE,
 	};
 
-	sink_runtime();
+	explicit sink_runtime(int fifo_length = 2 * 1024 * 1024);	/* base_sink_c_impl.cc:58 */
 	~sink_runtime();
 
 	/* base_sink_c_impl::work (base_sink_c_impl.cc:432-462): copies up to noutput_items samples
@@ -105,6 +113,8 @@ class sink_runtime
 
 	void worker();
 	void render();
+	void retire_uploads(bool wait_all);
+	void copy_helper(int idx);
 	void settings_mark_changed(uint32_t s);
 	uint32_t settings_get_and_reset_changed();
 	void settings_apply(uint32_t s);
@@ -121,6 +131,22 @@ class sink_runtime
 	struct { double center, span; } d_frequency;
 	float d_fft_window[1024]; bool d_have_window;
 	std::atomic<uint64_t> d_frames, d_samples;
+
+	/* uploads in flight: FIFO regions handed to fosphor_amd_process_pinned and not yet discarded */
+	enum { kMaxInflight = 32 };
+	struct { void *event; int len; } d_inflight[kMaxInflight];
+	int d_inflight_head, d_inflight_n, d_inflight_samples;
+	void *d_events[kMaxInflight];
+
+	/* helper threads for large copies in work() */
+	enum { kCopyHelpers = 3 };
+	struct copy_job { std::complex<float> *dst; const std::complex<float> *src; size_t n; int gen; };
+	std::thread d_copy_threads[kCopyHelpers];
+	copy_job d_copy_jobs[kCopyHelpers];
+	std::mutex d_copy_mutex;
+	std::condition_variable d_copy_cv, d_copy_done_cv;
+	int d_copy_gen, d_copy_pending;
+	bool d_copy_quit;
 };
 
 } // namespace fosphor_amd
@@ -150,6 +176,11 @@ void  fosphor_amd_fifo_read_discard(fosphor_amd_fifo *f, int size);
 
 typedef struct fosphor_amd_sink fosphor_amd_sink;
 fosphor_amd_sink *fosphor_amd_sink_new(void);
+/* same with a FIFO of `fifo_length` samples (power of two >= 32 Ki; the reference's is 2 Mi) */
+fosphor_amd_sink *fosphor_amd_sink_new_len(int fifo_length);
+/* Measurement: feeds `samples` (n complex samples) `repeats` times through work() from the calling thread, in
+ * calls of `chunk` samples, waits until everything has been processed, and returns the seconds it took. */
+double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, int chunk, int repeats);
 void  fosphor_amd_sink_free(fosphor_amd_sink *s);
 int   fosphor_amd_sink_start(fosphor_amd_sink *s);
 int   fosphor_amd_sink_stop(fosphor_amd_sink *s);

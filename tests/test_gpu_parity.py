@@ -696,6 +696,34 @@ def test_sink_waterfall_matches_oracle(amd, torch_cuda, oracle_built):
     L.fosphor_amd_sink_free(s)
 
 
+def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built):
+    """The sink fed from a native thread in large work() calls (helper-thread copies, several FIFO regions in
+    flight, regions discarded on their own upload events): every sample is processed exactly once and the final
+    rows equal the oracle's."""
+    import ctypes as C
+    L = amd.load()
+    n_spec = 4096 + 512
+    x = add_tone(gaussian_iq(n_spec * 1024, 51), 0.1, 0.33)
+    s = L.fosphor_amd_sink_new_len(1 << 22)
+    assert s and L.fosphor_amd_sink_new_len(1000) is None
+    assert L.fosphor_amd_sink_start(s) == 1
+    flat = np.ascontiguousarray(x).reshape(-1)
+    dt = L.fosphor_amd_sink_feed(s, flat.ctypes.data, n_spec * 1024, 1 << 20, 1)
+    assert dt > 0
+    samples = C.c_uint64()
+    L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+    assert samples.value == n_spec * 1024
+    core = L.fosphor_amd_sink_core(s)
+    wf = np.empty((1024, 1024), np.float32)
+    assert L.fosphor_amd_read(core, 0, wf.ctypes.data, wf.nbytes) == 0
+    o = Oracle()
+    for k in range(0, n_spec, 512):
+        o.process(x[k * 1024:(k + 512) * 1024], nthreads=8)
+    assert_close(wf, o.waterfall, "sink waterfall after a native feed")
+    L.fosphor_amd_sink_stop(s)
+    L.fosphor_amd_sink_free(s)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE config C3 geometry: N = 8192, 512 bins, 50 % overlap  (no reference behaviour exists
 # beyond N = 1024 / 128 bins: the oracle's generalisation defines it -- parity unpinned)
