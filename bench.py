@@ -59,10 +59,10 @@ CONFIGS = {
                text="C3: 8192-pt FFT, 50 %% overlap (overlap_cc(8192, 2) fused into the read), batch=4096 spectra, "
                     "8192x%(bins)d histogram + waterfall; one step = one fosphor_amd_process_device_overlap call of "
                     "%(bps)d such batches (%(msamp)d Mi FFT'd samples)"),
-    "C5": dict(log2n=16, bins=512, spb=128, bps=8, over=1, fp16=True,
-               text="C5: 65536-pt FFT, fp16 IQ, 65536x%(bins)d histogram + waterfall, per-GPU share of a sharded frame = "
-                    "batch of 128 spectra; one step = one fosphor_amd_process_device call of %(bps)d such batches "
-                    "(%(msamp)d Mi samples)"),
+    "C5": dict(log2n=16, bins=512, spb=1024, bps=1, over=1, fp16=True,
+               text="C5: 65536-pt FFT, fp16 IQ, 65536x%(bins)d histogram + waterfall; one step = one display frame of 1024 "
+                    "spectra (what the 8 GPUs of BASELINE configs[4] share 128 spectra each) as one batch on this GPU: one "
+                    "fosphor_amd_process_device call of %(bps)d such batch (%(msamp)d Mi samples), one state update"),
 }
 
 
@@ -164,7 +164,21 @@ def main():
         if not args.strict_ordering:
             f.set_input_ordering(False)		# the ring is written once, before the first call
     else:
-        sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw)
+        try:
+            sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw)
+            ok = 1
+        except Exception as e:			# the library's own RCCL communicator could not be set up on this rank
+            sys.stderr.write("rank %d: native exchange unavailable (%s)\n" % (rank, e))
+            sf, ok = None, 0
+        if world > 1:
+            # every rank must use the same transport: fall back together to torch.distributed's all-reduces
+            t_ok = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+            ok = int(t_ok.item())
+        if not ok:
+            if sf is not None:
+                sf.close()
+            sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", **kw)
         f = sf.f
         if not args.strict_ordering:
             f.set_input_ordering(False)
@@ -311,9 +325,11 @@ def main():
                 "input_ordering": "strict" if args.strict_ordering else "relaxed",
                 "host_submit_fraction": t_submit / elapsed,
                 "exchange": "none" if (sf is None or not sf.active) else
-                            "native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
-                            "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else
-                                                              "one ncclGroup of three all-reduces", F),
+                            ("native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
+                             "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else
+                                                               "one ncclGroup of three all-reduces", F))
+                            if sf.exchange == "rccl" else
+                            "torch.distributed all-reduces (RCCL) of hit counts / live sum / max once per frame of %d batches per GPU" % F,
             },
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -105,6 +105,8 @@ struct fosphor
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
+	uint16_t *d_slab16;			/* per-chunk packed 16-bit count slabs of batches longer than 1024 spectra / of a shard */
+	int       slab_chunks;			/* capacity of d_slab16 in 1024-spectrum chunks */
 	int       last_hc16;
 	float    *d_live_sum, *d_vmax;
 	float    *d_chunk_sum, *d_chunk_max;	/* [max_spectra/16][N] */
@@ -249,7 +251,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_h_free[i]) (void)hipEventDestroy(self->ev_h_free[i]);
 	}
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
-	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export);
+	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -397,6 +399,11 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
+	if (self->max_spectra > 1024) {
+		/* one slab per 1024-spectrum chunk of the largest launch: a whole shard (accumulate) or a sub-launch */
+		self->slab_chunks = self->max_spectra / 1024;
+		HIP_TRY(hipMalloc((void **)&self->d_slab16, sizeof(uint16_t) * (size_t)self->slab_chunks * self->n_bins * self->n), "alloc count slabs");
+	}
 	/* two sets of max_batches slots (the 16-bit hit counts of the second set use the upper half of d_hc) */
 	HIP_TRY(hipMalloc((void **)&self->d_live_sum, sizeof(float) * 2 * (size_t)self->max_batches * self->n), "alloc live sums");
 	HIP_TRY(hipMalloc((void **)&self->d_vmax, sizeof(float) * 2 * (size_t)self->max_batches * self->n), "alloc max");
@@ -649,11 +656,11 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	const int cpb = batch / chunk;
 	const size_t cells = (size_t)self->n_bins * self->n;
 
-	/* One batch of several chunks (the time shard of a display frame): K2 leaves per-chunk packed
-	 * 16-bit slabs in the upper half of d_hc (no zeroing, no global atomics) and k2c_sum adds them
-	 * into the 32-bit slot.  Needs whole 1024-spectrum chunks and room for cpb slabs. */
-	const int sum16 = (!use16 || batch > 1024) && n_batches == 1 && chunk == 1024 && cpb > 1 && cpb <= self->max_batches &&
-	                  self->max_batches >= 4 && !getenv("FOSPHOR_AMD_NO_SUM16");
+	/* Batches of several 1024-spectrum chunks (a batch longer than the reference's cap, or the time shard of
+	 * a display frame): K2 leaves per-chunk packed 16-bit slabs in d_slab16 (no zeroing, no global atomics)
+	 * and k2c_sum adds each batch's slabs into its 32-bit array.  Needs whole chunks and room for the slabs. */
+	const int sum16 = (!use16 || batch > 1024) && chunk == 1024 && cpb > 1 && self->d_slab16 &&
+	                  n_batches * cpb <= self->slab_chunks && !getenv("FOSPHOR_AMD_NO_SUM16");
 
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
@@ -661,13 +668,14 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch))
 	          ? (uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	if (sum16)
-		k2.hc16 = (uint16_t *)self->d_hc + (size_t)self->max_batches * cells;
+		k2.hc16 = self->d_slab16;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
+	k2.dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
 	if (cpb == 1) {
 		k2.chunk_sum = self->d_live_sum + (size_t)lslot * self->n;
 		k2.chunk_max = self->d_vmax + (size_t)lslot * self->n;
@@ -743,6 +751,7 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins; k3.n = self->n;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
 	k3.cell_begin = cell_begin; k3.cell_end = cell_end;
+	k3.dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
 	prof_begin(self, 2, st);
 	HIP_TRY(launch_k3(k3, st), "launch merge");
 	prof_end(self, st);
@@ -1172,7 +1181,7 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 		 * one k2c_sum at the end adds all of them into the 32-bit slot that is exchanged. */
 		const int cpb = n_local / 1024;
 		const size_t cells = (size_t)self->n_bins * self->n;
-		const int chunked = (n_local % 1024) == 0 && cpb > 1 && cpb <= self->max_batches && self->max_batches >= 4 &&
+		const int chunked = (n_local % 1024) == 0 && cpb > 1 && self->d_slab16 && cpb <= self->slab_chunks &&
 		                    !getenv("FOSPHOR_AMD_NO_SUM16");
 		long long per_chunk = 1024LL * self->n;
 		int sub_c = (int)(self->sub_samples / per_chunk);
@@ -1226,7 +1235,7 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 				memset(&k2, 0, sizeof(k2));
 				k2.bins = self->d_bins; k2.partial = self->d_partial;
 				k2.hc = self->d_hc + (size_t)self->slot * cells;
-				k2.hc16 = (uint16_t *)self->d_hc + ((size_t)self->max_batches + c0) * cells;
+				k2.hc16 = self->d_slab16 + (size_t)c0 * cells;
 				k2.n = self->n; k2.bins16 = self->bins16;
 				k2.batch = sub_total; k2.chunk = 1024; k2.tile = tile; k2.n_bins = self->n_bins;
 				k2.w = 1.0f - self->alpha;
@@ -1249,7 +1258,7 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 				k2b.live_sum = self->d_live_sum + (size_t)self->slot * self->n;
 				k2b.vmax = self->d_vmax + (size_t)self->slot * self->n;
 				k2b.n_batches = 1; k2b.cpb = cpb; k2b.n = self->n;
-				k2b.hc16 = (uint16_t *)self->d_hc + (size_t)self->max_batches * cells;
+				k2b.hc16 = self->d_slab16;
 				k2b.hc = self->d_hc + (size_t)self->slot * cells;
 				k2b.n_bins = self->n_bins;
 				HIP_TRY(launch_k2c(k2b, st2), "launch chunk sum");
@@ -1311,10 +1320,6 @@ error:
 extern "C" int fosphor_amd_set_partial_slot(struct fosphor *self, int slot)
 {
 	if (!self || slot < 0 || slot >= self->max_batches)
-		return -EINVAL;
-	/* the per-chunk 16-bit count slabs of a multi-chunk shard live in the upper half of the hit-count
-	 * array (run_count), i.e. in the memory of the 32-bit slots max_batches/2 and above */
-	if (self->max_batches >= 4 && slot >= self->max_batches / 2)
 		return -EINVAL;
 	self->slot = slot;
 	return 0;

@@ -81,6 +81,7 @@ struct K2Params {
 	/* sharded batch (multi-GPU): this launch holds spectra [t_offset, t_offset+batch)
 	 * of a batch of weight_batch spectra; single GPU: t_offset 0, weight_batch = batch */
 	int   t_offset, weight_batch;
+	int   dbg_same;			/* measurement only: every chunk reads and writes chunk 0's memory (no HBM traffic) */
 };
 
 struct K2bParams {
@@ -106,6 +107,7 @@ struct K3Params {
 	int   n_batches, batch, n_bins, n;
 	float t0r, t0d, alpha;
 	float live_decay;		/* (1-alpha)^batch */
+	int   dbg_same;			/* measurement only: every batch reads batch 0's counts */
 	int   cell_begin, cell_end;	/* cells [begin, end) of the (bin, x) array are updated (0, 0 = all): the
 					 * frequency-sliced merge of the multi-GPU split; the columns always are */
 };

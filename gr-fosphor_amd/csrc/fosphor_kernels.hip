@@ -281,6 +281,9 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #ifndef K1_LOAD16
 #define K1_LOAD16 1			/* 1: 16-byte IQ loads, lane L owns pass-1 items 2L and 2L+1; 0: 8-byte loads, items L and L+64 */
 #endif
+#ifndef K1_PRIO
+#define K1_PRIO 0
+#endif
 #ifndef K1_UNIFORM
 #define K1_UNIFORM 1			/* wave-uniform control values in SGPRs, in-place Horner, one branch for the row stores */
 #endif
@@ -338,6 +341,9 @@ void k1_fft_bin(const K1Params p)
 	__shared__ v2f   tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
 #endif
 
+#if K1_PRIO
+	__builtin_amdgcn_s_setprio(K1_PRIO);		/* K1's waves go first; the count / merge waves beside them take what is left */
+#endif
 	const int lane   = threadIdx.x & 63;
 #if K1_UNIFORM
 	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);	/* tile, spectrum index, row predicate: SGPRs */
@@ -1678,30 +1684,52 @@ void k1h_stage_b(const K1Params p)
 	}
 }
 
-static hipError_t launch_k1h(const K1Params &p, hipStream_t s)
+static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 {
 	constexpr size_t lds_a = ((size_t)16 * 513 + (8 + 64) * 7) * sizeof(float2);
+	constexpr int N = 65536;
 	static bool attr_set = false;
 	if (!attr_set) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
 		attr_set = true;
 	}
-	int blocks_a = p.total * 8;
-	if (blocks_a > 512) blocks_a = 512;			/* 2 work-groups of 64 KiB LDS per CU */
-	if (p.iq_half)
-		hipLaunchKernelGGL(k1h_stage_a<true>, dim3(blocks_a), dim3(1024), lds_a, s, p);
-	else
-		hipLaunchKernelGGL(k1h_stage_a<false>, dim3(blocks_a), dim3(1024), lds_a, s, p);
-	if (hipGetLastError() != hipSuccess)
-		return hipErrorLaunchFailure;
-	int blocks_b = (p.total / p.tile) * 16;
-	if (blocks_b > 512) blocks_b = 512;
-	if (p.fft_out)
-		hipLaunchKernelGGL(k1h_stage_b<true>, dim3(blocks_b), dim3(512), 0, s, p);
-	else
-		hipLaunchKernelGGL(k1h_stage_b<false>, dim3(blocks_b), dim3(512), 0, s, p);
-	return hipGetLastError();
+	/* Stage A and stage B alternate over groups of spectra whose intermediate (8 B per sample, fp32) fits the
+	 * Infinity Cache: the round trip between the stages then mostly stays on the die instead of costing 16 B of
+	 * HBM traffic per sample next to the 4 B of fp16 IQ.  Every group reuses the same scratch region. */
+	static const int group_env = [] { const char *e = getenv("FOSPHOR_AMD_K1H_GROUP"); return e ? atoi(e) : 0; }();
+	int group = group_env > 0 ? group_env : 128;			/* 128 x 512 KiB = 64 MiB of intermediate */
+	const int unit = p0.tile > 2 ? p0.tile : 2;			/* whole tiles, whole index dwords */
+	group -= group % unit;
+	if (group < unit) group = unit;
+	for (int s0 = 0; s0 < p0.total; s0 += group) {
+		K1Params p = p0;
+		p.total = (p0.total - s0 < group) ? p0.total - s0 : group;
+		p.iq = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(p0.iq) + (size_t)s0 * p0.hop * (p0.iq_half ? 4 : 8));
+		p.bins = p0.bins + (size_t)(s0 >> 1) * N;
+		p.partial = p0.partial + (size_t)(s0 / p0.tile) * N;
+		p.wf_pos0 = p0.wf_pos0 + s0;
+		p.wf_first = p0.wf_first - s0;
+		if (p.wf_first < 0) p.wf_first = 0;
+		if (p0.fft_out) p.fft_out = p0.fft_out + (size_t)s0 * N;
+		int blocks_a = p.total * 8;
+		if (blocks_a > 512) blocks_a = 512;			/* 2 work-groups of 64 KiB LDS per CU */
+		if (p.iq_half)
+			hipLaunchKernelGGL(k1h_stage_a<true>, dim3(blocks_a), dim3(1024), lds_a, s, p);
+		else
+			hipLaunchKernelGGL(k1h_stage_a<false>, dim3(blocks_a), dim3(1024), lds_a, s, p);
+		if (hipGetLastError() != hipSuccess)
+			return hipErrorLaunchFailure;
+		int blocks_b = (p.total / p.tile) * 16;
+		if (blocks_b > 512) blocks_b = 512;
+		if (p.fft_out)
+			hipLaunchKernelGGL(k1h_stage_b<true>, dim3(blocks_b), dim3(512), 0, s, p);
+		else
+			hipLaunchKernelGGL(k1h_stage_b<false>, dim3(blocks_b), dim3(512), 0, s, p);
+		if (hipGetLastError() != hipSuccess)
+			return hipErrorLaunchFailure;
+	}
+	return hipSuccess;
 }
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s)
@@ -1840,7 +1868,7 @@ void k2_count(const K2Params p)
 	const int lane = tid & 63;
 	const int wv   = tid >> 6;
 	const int x0   = blockIdx.x * 64;
-	const int c    = blockIdx.y;			/* chunk index within the launch */
+	const int c    = p.dbg_same ? 0 : blockIdx.y;	/* chunk index within the launch */
 	const int cpb  = p.batch / p.chunk;		/* chunks per batch */
 	const int f    = c / cpb;			/* batch index */
 	const int t_in = (c - f * cpb) * p.chunk;	/* first spectrum of the chunk within its batch */
@@ -2005,12 +2033,13 @@ void k2c_sum(const K2bParams p)
 	const int pairs = p.n_bins * p.n / 2;		/* dwords per chunk slab set: columns c, c + 32 packed */
 	const int cells = pairs;			/* thread index space: one thread per packed pair */
 	const int gid = blockIdx.x * 256 + threadIdx.x;
+	const int f = blockIdx.y;			/* batch of the launch */
 	if (gid < pairs) {
 		const int nb = p.n_bins;
 		const int slab = gid / (nb * 32);
 		const int rem = gid - slab * nb * 32;
 		const int bin = rem >> 5, hcol = rem & 31;
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.hc16) + gid;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.hc16) + (size_t)f * p.cpb * pairs + gid;
 		uint32_t lo = 0, hi = 0;
 		int c = 0;
 		for (; c + 8 <= p.cpb; c += 8) {
@@ -2029,19 +2058,20 @@ void k2c_sum(const K2bParams p)
 			lo += v & 0xffffu;
 			hi += v >> 16;
 		}
-		uint32_t *dst = p.hc + bin * p.n + slab * 64 + hcol;
+		uint32_t *dst = p.hc + (size_t)f * p.n_bins * p.n + bin * p.n + slab * 64 + hcol;
 		dst[0]  = lo;
 		dst[32] = hi;
 	} else if (gid < cells + p.n) {
 		const int x = gid - cells;
+		const float *cs = p.chunk_sum + (size_t)f * p.cpb * p.n, *cm = p.chunk_max + (size_t)f * p.cpb * p.n;
 		float s = 0.0f, m = -1000.0f;
 		int c = 0;
 		for (; c + 8 <= p.cpb; c += 8) {
 			float a[8], b[8];
 #pragma unroll
 			for (int u = 0; u < 8; u++) {
-				a[u] = p.chunk_sum[(size_t)(c + u) * p.n + x];
-				b[u] = p.chunk_max[(size_t)(c + u) * p.n + x];
+				a[u] = cs[(size_t)(c + u) * p.n + x];
+				b[u] = cm[(size_t)(c + u) * p.n + x];
 			}
 #pragma unroll
 			for (int u = 0; u < 8; u++) {		/* same order as k2b_reduce */
@@ -2050,18 +2080,18 @@ void k2c_sum(const K2bParams p)
 			}
 		}
 		for (; c < p.cpb; c++) {
-			s += p.chunk_sum[(size_t)c * p.n + x];
-			m = (m < p.chunk_max[(size_t)c * p.n + x]) ? p.chunk_max[(size_t)c * p.n + x] : m;
+			s += cs[(size_t)c * p.n + x];
+			m = (m < cm[(size_t)c * p.n + x]) ? cm[(size_t)c * p.n + x] : m;
 		}
-		p.live_sum[x] = s;
-		p.vmax[x] = m;
+		p.live_sum[(size_t)f * p.n + x] = s;
+		p.vmax[(size_t)f * p.n + x] = m;
 	}
 }
 
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
 {
 	const int threads = p.n_bins * p.n / 2 + p.n;
-	hipLaunchKernelGGL(k2c_sum, dim3((threads + 255) / 256), dim3(256), 0, s, p);
+	hipLaunchKernelGGL(k2c_sum, dim3((threads + 255) / 256, p.n_batches), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 
@@ -2108,7 +2138,7 @@ void k3_merge(const K3Params p)
 				uint32_t hc[8];
 #pragma unroll
 				for (int u = 0; u < 8; u++)
-					hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(f + u) * cells + gid]);
+					hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
 #pragma unroll
 				for (int u = 0; u < 8; u++) {
 					if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */

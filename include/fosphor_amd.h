@@ -120,7 +120,7 @@ int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *
 int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
                                   int n_local, int t_offset, int total_batch);
 
-/* Select which of the instance's partial-array slots (0 .. max_batches/2 - 1) the next
+/* Select which of the instance's partial-array slots (0 .. max_batches - 1) the next
  * accumulate / get_partials / merge use.  Two slots let the all-reduce of frame k overlap the
  * FFT of frame k+1. */
 int fosphor_amd_set_partial_slot(struct fosphor *self, int slot);
