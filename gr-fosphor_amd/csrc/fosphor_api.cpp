@@ -385,7 +385,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
 		self->overlap = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_K1");
-		self->k1_variant = (e && *e == '2') ? 2 : (e && *e == '5') ? 5 : (e && *e == '6') ? 6 : 1;
+		self->k1_variant = (e && *e == '2') ? 2 : (e && *e == '5') ? 5 : (e && *e == '6') ? 6 : (e && *e == '7') ? 7 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
 		self->pipe3 = (e && *e == '1');
 		e = getenv("FOSPHOR_AMD_ALT");
@@ -640,7 +640,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : (self->log2n == 16 ? 4 : 3);
 	k1->scratch = self->d_scratch;
 	k1->iq_half = self->iq_half;
-	if ((k1->variant == 1 || k1->variant == 5 || k1->variant == 6) && (k1->hop & 1))
+	if ((k1->variant == 1 || k1->variant >= 5) && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
 

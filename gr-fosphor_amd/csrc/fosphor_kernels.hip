@@ -976,6 +976,317 @@ void k1d_fft_bin(const K1Params p)
 }
 
 /* ------------------------------------------------------------------------ */
+/* K1, three waves per SIMD                                                    */
+/* ------------------------------------------------------------------------ */
+/* K1 is bound by the issue rate of its own instruction stream at two waves per SIMD: the
+ * VALU pipe needs ~2270 cycles per spectrum and gets a spectrum every ~4200, because two waves cannot cover
+ * each other's LDS round trips and dependent chains.  A third wave needs <= 168 registers per lane.  What goes:
+ *   - the 32 registers of the next spectrum's IQ: the spectrum is fetched by LDS-DMA (global_load_lds_dwordx4,
+ *     8 x 1 KiB, non-temporal) straight into the wave's exchange slab, issued once the current spectrum no longer
+ *     needs the slab (after its last exchange read; passes 3-4 and the epilogue run out of registers) -- no second
+ *     slab, so 12 waves x 8 KiB still fit a CU beside the tables and K2;
+ *   - the 28 registers of the pass-2/3 twiddles: work-group LDS tables (as in k1d_fft_bin).
+ * Pass 1 reads its inputs back from the slab (8 ds_read_b128 per lane: elements (2L, 2L+1) + 128 q land at byte
+ * 16 L + 1024 q, which is exactly the register layout of the 16-byte loads).  Work-groups of 6 waves (two per CU:
+ * 2 x 60 KiB of LDS + 32 KiB for K2).  Same arithmetic, same outputs as k1_fft_bin. */
+template <bool WRITE_FFT>
+__global__ __launch_bounds__(384, 3)
+void k1t_fft_bin(const K1Params p)
+{
+	__shared__ v2f   lds[6][kN];			/* 8 KiB slab per wave: landing zone AND exchange buffer */
+	__shared__ v2f   tw4_tab[512];
+	__shared__ float win_tab[kN];
+	__shared__ v2f   tw3_tab[7][64];
+	__shared__ v2f   tw2_tab[7][8];
+
+	const int lane   = threadIdx.x & 63;
+	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int ntiles = p.total / p.tile;
+	const int stride = gridDim.x * 6;		/* waves in the grid */
+	const int tile0  = blockIdx.x * 6 + wv;
+	const int T      = p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+
+	for (int i = threadIdx.x; i < kN; i += 384)
+		win_tab[i] = p.win[i];
+	for (int i = threadIdx.x; i < 512; i += 384)
+		tw4_tab[i] = twg[kTw4Off + i];
+	for (int i = threadIdx.x; i < 7 * 64; i += 384)
+		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
+	if (threadIdx.x < 56)
+		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
+	__syncthreads();				/* the only block-wide barrier */
+
+	if (tile0 >= ntiles)
+		return;					/* whole wave leaves */
+
+	v2f *buf = lds[wv];
+	const uint32_t slab = (uint32_t)reinterpret_cast<uintptr_t>(buf) + 16 * lane;	/* LDS byte address of this lane's pair */
+	const uint32_t tw3_addr = (uint32_t)reinterpret_cast<uintptr_t>(&tw3_tab[0][lane]);	/* [n][lane]: 512 B per n */
+	const uint32_t tw4_addr = (uint32_t)reinterpret_cast<uintptr_t>(&tw4_tab[lane]);	/* [lane + 64 c]: 512 B per c */
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+
+	const int rd_even = lane ^ ((lane >> 3) & 7);
+	const int rd_odd  = rd_even ^ 8;
+	const int st1a    = (16 * lane) ^ ((2 * lane) & 15);
+	const int st1b    = (16 * lane + 8) ^ ((2 * lane + 1) & 15);
+	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);
+
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	auto spectrum_of = [&](int k, int *tile_out) -> int {
+		const int j = k / T;
+		const int tile = tile0 + j * stride;
+		*tile_out = tile;
+		return tile * T + (k - j * T);
+	};
+	/* ALWAYS eight requests (the hand-counted wait relies on it); past the end: the launch's first spectrum */
+	auto request = [&](int k) {
+		int tile;
+		int t = spectrum_of(k, &tile);
+		if (tile >= ntiles)
+			t = 0;
+		const float2 *src = p.iq + (size_t)t * p.hop + 2 * lane;
+		float *dst = reinterpret_cast<float *>(buf);
+		__builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);
+		__builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 2);
+		__builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 2);
+		__builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 2);
+		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 0, 2);
+		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 1024, 2);
+		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 2048, 2);
+		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 3072, 2);
+	};
+
+	float live[16], vmax[16];
+	uint32_t pack[16];
+
+	request(0);
+	{
+		/* 16 stores behind the first request, as every group of four spectra leaves them behind the request of
+		 * its successor (the wait count of a group's first spectrum then holds from the start) */
+		uint32_t *dst = p.bins + (size_t)((tile0 * T) >> 2) * kN + lane;
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			dst[64 * m] = 0;
+	}
+
+	for (int k = 0; ; k++) {
+		int tile;
+		const int t = spectrum_of(k, &tile);
+		if (tile >= ntiles)
+			break;
+		const int g = t - tile * T;		/* position in the tile */
+		const int u = g & 3;
+		v2f x[16];
+
+		if (g == 0) {
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				live[m] = 0.0f;
+				vmax[m] = vmax_init;
+			}
+		}
+		if (u == 0) {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				pack[m] = 0;
+		}
+
+		/* younger than this spectrum's request: the 16 bin-index stores of the group that just closed (the
+		 * rare row / partial stores only make the wait longer than needed) */
+		if (u == 0)
+			asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+		else
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		{
+			v4f q[8];
+			asm volatile("ds_read_b128 %0, %8\n\t"
+			             "ds_read_b128 %1, %8 offset:1024\n\t"
+			             "ds_read_b128 %2, %8 offset:2048\n\t"
+			             "ds_read_b128 %3, %8 offset:3072\n\t"
+			             "ds_read_b128 %4, %8 offset:4096\n\t"
+			             "ds_read_b128 %5, %8 offset:5120\n\t"
+			             "ds_read_b128 %6, %8 offset:6144\n\t"
+			             "ds_read_b128 %7, %8 offset:7168\n\t"
+			             "s_waitcnt lgkmcnt(0)"
+			             : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+			             : "v"(slab) : "memory");
+			/* window (fft.cl:415-417); taps fetched as pairs */
+#pragma unroll
+			for (int j = 0; j < 8; j++) {
+				const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * j]);
+				x[2 * j]     = mul_bcast_lo(v2f{ q[j].x, q[j].y }, w);
+				x[2 * j + 1] = mul_bcast_hi(v2f{ q[j].z, q[j].w }, w);
+			}
+		}
+
+		/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) */
+#pragma unroll
+		for (int v = 0; v < 2; v++) {
+			v2f r[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = x[v + 2 * j];
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
+		wave_lds_sync();
+
+		/* ---- pass 2: radix 8, p = 8 (fft.cl:422-423) */
+		{
+			v2f tw2[7];
+#pragma unroll
+			for (int n = 0; n < 7; n++)
+				tw2[n] = tw2_tab[n][lane & 7];
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				v2f r[8];
+				r[0] = x[v];
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					buf[(st2 ^ (9 * jj)) + 512 * v] = r[R8_PERM(jj)];
+			}
+		}
+		wave_lds_sync();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
+		wave_lds_sync();
+		/* the slab is not touched again by this spectrum (the third exchange is register renaming): it takes the
+		 * next one now.  The table reads below are asm so that the compiler does not drain the request in front
+		 * of them (it cannot tell an LDS-DMA target from any other LDS address). */
+		pin16(x);
+		request(k + 1);
+
+		/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426); the third exchange is register renaming */
+		{
+			v2f y[16];
+			v2f tw3[7];
+			asm volatile("ds_read_b64 %0, %7\n\t"
+			             "ds_read_b64 %1, %7 offset:512\n\t"
+			             "ds_read_b64 %2, %7 offset:1024\n\t"
+			             "ds_read_b64 %3, %7 offset:1536\n\t"
+			             "ds_read_b64 %4, %7 offset:2048\n\t"
+			             "ds_read_b64 %5, %7 offset:2560\n\t"
+			             "ds_read_b64 %6, %7 offset:3072\n\t"
+			             "s_waitcnt lgkmcnt(0)"
+			             : "=&v"(tw3[0]), "=&v"(tw3[1]), "=&v"(tw3[2]), "=&v"(tw3[3]), "=&v"(tw3[4]), "=&v"(tw3[5]), "=&v"(tw3[6])
+			             : "v"(tw3_addr) : "memory");
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				v2f r[8];
+				r[0] = x[v];
+#pragma unroll
+				for (int j = 1; j < 8; j++)
+					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					y[jj + 8 * v] = r[R8_PERM(jj)];
+			}
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				x[m] = y[m];
+		}
+
+		/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) */
+		{
+			v2f tw4[8];
+			asm volatile("ds_read_b64 %0, %8\n\t"
+			             "ds_read_b64 %1, %8 offset:512\n\t"
+			             "ds_read_b64 %2, %8 offset:1024\n\t"
+			             "ds_read_b64 %3, %8 offset:1536\n\t"
+			             "ds_read_b64 %4, %8 offset:2048\n\t"
+			             "ds_read_b64 %5, %8 offset:2560\n\t"
+			             "ds_read_b64 %6, %8 offset:3072\n\t"
+			             "ds_read_b64 %7, %8 offset:3584\n\t"
+			             "s_waitcnt lgkmcnt(0)"
+			             : "=&v"(tw4[0]), "=&v"(tw4[1]), "=&v"(tw4[2]), "=&v"(tw4[3]), "=&v"(tw4[4]), "=&v"(tw4[5]), "=&v"(tw4[6]), "=&v"(tw4[7])
+			             : "v"(tw4_addr) : "memory");
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				v2f a = x[c];
+				v2f b = c_mul(x[c + 8], tw4[c]);
+				DFT2(a, b);
+				x[c] = a;
+				x[c + 8] = b;
+			}
+		}
+
+		if (WRITE_FFT) {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * m] = x[m];
+		}
+
+		/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) */
+		float    l2[16];
+		uint32_t amb = 0;
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			uint32_t ab;
+			const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
+			amb = amb > ab ? amb : ab;
+			pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+		}
+		if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+			for (int m = 0; m < 16; m++) {
+				const float v = __builtin_fmaf(bk.A, l2[m], bk.C);
+				const float r = __builtin_rintf(v);
+				const float a = __builtin_fmaf(__builtin_fabsf(l2[m]), bk.kappa, __builtin_fabsf(v - r));
+				if (!(a <= bk.amb)) {
+					const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
+					float nl2;
+					const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
+					pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
+					l2[m] = nl2;
+				}
+			}
+		}
+#pragma unroll
+		for (int m = 0; m < 16; m++) {
+			asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
+			vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
+		}
+		if (t >= p.wf_first) {				/* uniform: one scalar branch */
+			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
+		}
+		if (u == 3) {
+			uint32_t *dst = p.bins + (size_t)(t >> 2) * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				dst[64 * m] = pack[m];
+		}
+		if (g == T - 1) {
+			float2 *pp = p.partial + (size_t)tile * kN + lane;
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				pp[64 * m] = make_float2(live[m] * F_HALF_LOG10_2,
+				                         (vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
+		}
+	}
+	/* the request past the last spectrum still targets this wave's LDS: it must land before the wave ends */
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+/* ------------------------------------------------------------------------ */
 /* K1's memory traffic without K1's arithmetic (measurement hook)             */
 /* ------------------------------------------------------------------------ */
 /* The same persistent grid, tile order, 16-byte non-temporal loads one spectrum ahead, and the same
@@ -1775,6 +2086,16 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			hipLaunchKernelGGL(k1v2_fft_bin<true>, dim3(blocks), dim3(128), 0, s, p);
 		else
 			hipLaunchKernelGGL(k1v2_fft_bin<false>, dim3(blocks), dim3(128), 0, s, p);
+		return hipGetLastError();
+	}
+	if (p.variant == 7) {
+		int blocks = (tiles + 5) / 6;
+		if (blocks > 512)
+			blocks = 512;			/* two 6-wave work-groups per CU */
+		if (p.fft_out)
+			hipLaunchKernelGGL(k1t_fft_bin<true>, dim3(blocks), dim3(384), 0, s, p);
+		else
+			hipLaunchKernelGGL(k1t_fft_bin<false>, dim3(blocks), dim3(384), 0, s, p);
 		return hipGetLastError();
 	}
 	if (p.variant == 5 || p.variant == 6) {

@@ -2,7 +2,7 @@
 """One-off large-sample parity check (not part of the test suite: ~10^9 samples): hit counts of every batch
 against the oracle, bit for bit, for several seeds / signal mixes / power ranges, at 128 and 256 bins.
 
-    python3 tests/soak_parity.py [n_seeds [c2|c3|c5]]          (kept under tests/: it uses the oracle as the checker)
+    python3 tests/soak_parity.py [n_seeds [c2|c3|c5|pipe]]          (kept under tests/: it uses the oracle as the checker)
 """
 import os
 import sys
@@ -82,7 +82,45 @@ def main(n_seeds):
     return 1 if mismatched else 0
 
 
+def pipe(n_calls):
+    """the device-resident path at the bench's call size: 256 batches of 1024 spectra per call, sub-launched 64 at a
+    time with the K1s on alternating streams, relaxed ordering.  Only the last batch's counts of a call are visible,
+    but every batch's counts feed the histogram state: final counts bit-exact, state in tolerance after every call."""
+    build_oracle(ref=False)
+    threads = min(os.cpu_count() or 1, 64)
+    F, B = 256, 1024
+    f = gr_fosphor_amd.Fosphor(n_bins=256, max_spectra=F * B, max_batches=F)
+    f.set_input_ordering(False)
+    o = Oracle(n_bins=256)
+    rng = np.random.default_rng(4242)
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    bad_cells = bad_state = 0
+    t0 = time.time()
+    keep = []
+    for call in range(n_calls):
+        d = torch.empty((F * B * 1024, 2), dtype=torch.float32, device="cuda").normal_(0.0, [0.05, 0.5, 0.003][call % 3], generator=g)
+        if call & 1:
+            t = torch.arange(F * B * 1024, device="cuda", dtype=torch.float32)
+            d[:, 0] += 0.2 * torch.cos(0.37 * (call + 1) * t); d[:, 1] += 0.2 * torch.sin(0.37 * (call + 1) * t)
+        torch.cuda.synchronize()
+        keep = [d]
+        assert f.process_device(d, F, B) == 0
+        x = d.cpu().numpy()
+        for k in range(F):
+            assert o.process(x[k * B * 1024:(k + 1) * B * 1024], nthreads=threads) == 0
+        bad = int((f.hitcount != o.hitcount.T).sum())
+        hist_bad = int((np.abs(f.histogram - o.histogram) > 2e-6 + 1e-4 * np.abs(o.histogram)).sum())
+        live_bad = int((~np.isclose(f.spectrum[..., 1], o.spectrum[..., 1], rtol=1e-4, atol=1e-6)).sum())
+        wf_bad = int((~np.isclose(f.waterfall, o.waterfall, rtol=1e-4, atol=1e-6)).sum())
+        bad_cells += bad; bad_state += hist_bad + live_bad + wf_bad
+        print("call %d: %d count cells, %d histogram cells, %d spectrum values, %d waterfall texels differ" % (call, bad, hist_bad, live_bad, wf_bad), flush=True)
+    print("pipeline: %d samples in %d calls of %d batches, %d mismatching hit-count cells, %d state values out of tolerance, %.0f s"
+          % (n_calls * F * B * 1024, n_calls, F, bad_cells, bad_state, time.time() - t0))
+    f.close()
+    return 1 if (bad_cells or bad_state) else 0
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     which = sys.argv[2] if len(sys.argv) > 2 else "c2"
-    sys.exit(main(n) if which == "c2" else big(n, 13, False) if which == "c3" else big(n, 16, True))
+    sys.exit(main(n) if which == "c2" else pipe(n) if which == "pipe" else big(n, 13, False) if which == "c3" else big(n, 16, True))

@@ -270,12 +270,13 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
 
 
 @pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"},
-                                 {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K23": "1"},
+                                 {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K1": "7"}, {"FOSPHOR_AMD_K23": "1"},
                                  {"FOSPHOR_AMD_ALT": "0"}, {"FOSPHOR_AMD_TILE": "16"}, {"FOSPHOR_AMD_SUB_LOG2": "17"},
                                  {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"}])
 def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
     """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the K1 variants
-    (two waves per spectrum; asm-prefetched, one or two spectra ahead), the fused count+merge kernel, the tile
+    (two waves per spectrum; asm-prefetched, one or two spectra ahead; three waves per SIMD with the IQ landing in the
+    exchange slab by LDS-DMA), the fused count+merge kernel, the tile
     length, sub-launches of one batch on alternating FFT streams (with and without stream ordering against the
     caller) are scheduling choices: several back-to-back launches, then a switch to the sharded path and back,
     must leave exactly the state of the sequential reference calls."""
