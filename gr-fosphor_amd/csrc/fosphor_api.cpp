@@ -395,7 +395,9 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		e = getenv("FOSPHOR_AMD_K23");
 		self->k23 = (e && *e == '1');
 		e = getenv("FOSPHOR_AMD_SUB_LOG2");		/* tuning: log2 of the samples per sub-launch */
-		self->sub_samples = 1LL << ((e && atoi(e) >= 14 && atoi(e) <= 34) ? atoi(e) : kSubSamplesLog2);
+		/* (N = 8192: the one-work-group-per-CU FFT kernel owns the whole LDS, so K2 cannot run beside it and a
+		 * smaller piece only adds serialised kernel boundaries: twice the default) */
+		self->sub_samples = 1LL << ((e && atoi(e) >= 14 && atoi(e) <= 34) ? atoi(e) : kSubSamplesLog2 + (self->log2n == 13 ? 1 : 0));
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
@@ -644,6 +646,14 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
 
+/* A batch longer than 1024 spectra is counted as ONE chunk where that still gives the chip enough work-groups
+ * (N/64 slabs per batch) and the (d, e) table covers it: the 16-bit packed counters hold up to 65535 spectra, and K3
+ * then reads slab-major 16-bit counts (0.5 B per cell) instead of 32-bit sums of per-chunk slabs. */
+static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
+{
+	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !getenv("FOSPHOR_AMD_NO_BIGCHUNK");
+}
+
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
@@ -652,7 +662,8 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
                      int t_offset, int weight_batch, hipStream_t st, int use16 = 0, int hset = 0)
 {
 	K2Params k2; K2bParams k2b;
-	const int chunk = batch <= 1024 ? batch : gcd_int(batch, 1024);
+	const int one_chunk = use16 && count_one_chunk(self, batch, n_batches);
+	const int chunk = (batch <= 1024 || one_chunk) ? batch : gcd_int(batch, 1024);
 	const int cpb = batch / chunk;
 	const size_t cells = (size_t)self->n_bins * self->n;
 
@@ -665,7 +676,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
-	k2.hc16 = (use16 && batch <= 1024 && self->rise_ok(batch))
+	k2.hc16 = (use16 && (batch <= 1024 || one_chunk) && self->rise_ok(batch))
 	          ? (uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	if (sum16)
 		k2.hc16 = self->d_slab16;
@@ -742,7 +753,8 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.rise = have_table ? self->d_rise : NULL;
 	k3.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
 	k3.hc = self->d_hc + (size_t)slot0 * cells;
-	k3.hc16 = (use16 && batch <= 1024 && have_table)
+	const int one_chunk = use16 && count_one_chunk(self, batch, n_batches);
+	k3.hc16 = (use16 && (batch <= 1024 || one_chunk) && have_table)
 	          ? (const uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	k3.hc_export = self->d_hc_export;
 	k3.live_sum = self->d_live_sum + (size_t)lslot * self->n;
@@ -939,7 +951,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		HIP_TRY(hipEventRecord(self->ev_alt_done, self->stream_alt), "record second FFT stream");
 		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_alt_done, 0), "stream waits for the second FFT stream");
 	}
-	self->last_hc16 = (batch <= 1024 && batch <= kRiseMax);
+	self->last_hc16 = (batch <= 1024 || count_one_chunk(self, batch, self->last_batches));
 
 	self->wf_pos = (self->wf_pos + total) & (self->wf_rows - 1);	/* cl.c:954 */
 	self->last_slot0 = 0;

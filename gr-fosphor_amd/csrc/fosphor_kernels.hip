@@ -2420,7 +2420,8 @@ hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
 /* K3: state update                                                          */
 /* ------------------------------------------------------------------------ */
 
-/* MODE 0: 16-bit slab-major counts + LDS (d, e) table; 1: 32-bit counts + (d, e) table in memory;
+/* MODE 0: 16-bit slab-major counts + LDS (d, e) table (batch <= 1024); 3: the same counts, table in memory
+ * (batches of up to 8192 spectra counted as one chunk); 1: 32-bit counts + (d, e) table in memory;
  * 2: 32-bit counts, (d, e) evaluated per cell (batches beyond the table).  Separate instantiations keep
  * the common one (0) at a register budget that lets it share a SIMD with K1. */
 template <int MODE>
@@ -2440,7 +2441,7 @@ void k3_merge(const K3Params p)
 	}
 
 	for (int gid = blockIdx.x * 256 + threadIdx.x; gid < cells + p.n; gid += gridDim.x * 256) {
-	if (MODE == 0) {
+	if (MODE == 0 || MODE == 3) {
 		/* 16-bit slab-major counts as K2 leaves them ([slab of 64 columns][bin][32] dwords, columns
 		 * c and c + 32 in the low / high half): thread gid reads the gid-th 16-bit word of a batch
 		 * (2 B per batch, 8 batches in flight); the (d, e) table sits in LDS (one dependent lookup
@@ -2463,7 +2464,7 @@ void k3_merge(const K3Params p)
 #pragma unroll
 				for (int u = 0; u < 8; u++) {
 					if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
-						const float2 de = rise_lds[hc[u]];
+						const float2 de = (MODE == 0) ? rise_lds[hc[u]] : p.rise[hc[u]];
 						hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
 						hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
 						hv = (1.0f < hv) ? 1.0f : hv;
@@ -2474,7 +2475,7 @@ void k3_merge(const K3Params p)
 			for (; f < p.n_batches; f++) {
 				const uint32_t hc = p.hc16[(size_t)f * cells + gid];
 				if (!((hv <= 0.01f) && (hc == 0))) {
-					const float2 de = rise_lds[hc];
+					const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
 					hv = (hv - de.x) * de.y + de.x;
 					hv = (hv < 0.0f) ? 0.0f : hv;
 					hv = (1.0f < hv) ? 1.0f : hv;
@@ -2485,7 +2486,7 @@ void k3_merge(const K3Params p)
 			p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers) */
 		}
 	}
-	if (MODE == 0) {
+	if (MODE == 0 || MODE == 3) {
 		/* cells handled above */
 	} else if (gid < cells && (p.cell_end == 0 || (gid >= p.cell_begin && gid < p.cell_end))) {
 		/* one (bin, x) cell; batches applied in order (display.cl:217-254).
@@ -2570,8 +2571,10 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 	const int threads = p.n_bins * p.n + p.n;
 	int blocks = (threads + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	if (p.hc16)
+	if (p.hc16 && p.batch <= 1024)
 		hipLaunchKernelGGL(k3_merge<0>, dim3(blocks), dim3(256), 0, s, p);
+	else if (p.hc16)
+		hipLaunchKernelGGL(k3_merge<3>, dim3(blocks), dim3(256), 0, s, p);
 	else if (p.rise)
 		hipLaunchKernelGGL(k3_merge<1>, dim3(blocks), dim3(256), 0, s, p);
 	else
