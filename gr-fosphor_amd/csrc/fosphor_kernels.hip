@@ -1778,7 +1778,7 @@ void k1big_fft_bin(const K1Params p)
  * (8 B per sample written and read).  Arithmetic: the same c_mul / dft8 / DFT2 as every other variant,
  * hence the same bits as the oracle.  fp16 IQ is widened on load (exact). */
 template <bool HALF>
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(1024, 8)		/* <= 64 VGPRs: two 16-wave work-groups per CU (68 left room for one) */
 void k1h_stage_a(const K1Params p)
 {
 	constexpr int N = 65536, QA = 16, M = 512, TS = 64, ROW = M + 1;
