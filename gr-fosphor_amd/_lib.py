@@ -137,6 +137,9 @@ SIGNATURES = {
     "fosphor_amd_sink_stop": (C.c_int, [C.c_void_p]),
     "fosphor_amd_sink_work": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "fosphor_amd_sink_ui_action": (None, [C.c_void_p, C.c_int]),
+    "fosphor_amd_sink_reshape": (None, [C.c_void_p, C.c_int, C.c_int]),
+    "fosphor_amd_sink_mouse_action": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "fosphor_amd_sink_get_render": (None, [C.c_void_p, C.c_int, C.POINTER(Render)]),
     "fosphor_amd_sink_set_frequency_range": (None, [C.c_void_p, C.c_double, C.c_double]),
     "fosphor_amd_sink_set_fft_window": (None, [C.c_void_p, C.c_void_p]),
     "fosphor_amd_sink_set_visible": (None, [C.c_void_p, C.c_int]),

@@ -103,7 +103,8 @@ std::complex<float> *fifo::peek_at(int offset)
 const int sink_runtime::k_db_per_div[5] = {1, 2, 5, 10, 20};		/* base_sink_c_impl.cc:48 */
 
 sink_runtime::sink_runtime(int fifo_length)
-  : d_fosphor(nullptr), d_active(false), d_frozen(false), d_visible(true), d_draining(false),
+  : d_fosphor(nullptr), d_width(1024), d_height(1024), d_freq_cb(nullptr), d_freq_user(nullptr),
+    d_active(false), d_frozen(false), d_visible(true), d_draining(false),
     d_settings_changed(0), d_db_ref(0), d_db_per_div_idx(3),
     d_zoom_enabled(false), d_zoom_center(0.5), d_zoom_width(0.2), d_ratio(0.35f),
     d_have_window(false), d_frames(0), d_samples(0),
@@ -115,6 +116,9 @@ sink_runtime::sink_runtime(int fifo_length)
 	d_fifo = new fifo(fifo_length, true);				/* base_sink_c_impl.cc:58 */
 	d_render_main = new fosphor_render();
 	fosphor_render_defaults(d_render_main);				/* :61-62 */
+	d_render_zoom = new fosphor_render();
+	fosphor_render_defaults(d_render_zoom);				/* :64-66 */
+	d_render_zoom->options &= ~(FRO_LABEL_PWR | FRO_LABEL_TIME);
 	for (int i = 0; i < kMaxInflight; i++)
 		d_events[i] = nullptr;
 	for (int i = 0; i < kCopyHelpers; i++) {
@@ -136,6 +140,7 @@ sink_runtime::~sink_runtime()
 	for (int i = 0; i < kMaxInflight; i++)
 		if (d_events[i])
 			(void)hipEventDestroy((hipEvent_t)d_events[i]);
+	delete d_render_zoom;
 	delete d_render_main;
 	delete d_fifo;
 }
@@ -203,13 +208,58 @@ void sink_runtime::settings_apply(uint32_t s)				/* :220-288, compute-relevant p
 		fosphor_set_frequency_range(d_fosphor, d_frequency.center, d_frequency.span);
 	if ((s & SETTING_FFT_WINDOW) && d_have_window)
 		fosphor_set_fft_window(d_fosphor, d_fft_window);
-	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS)) {
+	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS)) {		/* :257-289 */
+		if (d_zoom_enabled) {
+			int a = (int)(d_width * 0.65f);
+			d_render_main->width = a;
+			d_render_main->options |= FRO_CHANNELS;
+			d_render_main->options &= ~FRO_COLOR_SCALE;
+			d_render_zoom->pos_x = a - 10;
+			d_render_zoom->width = d_width - a + 10;
+		} else {
+			d_render_main->width = d_width;
+			d_render_main->options &= ~FRO_CHANNELS;
+			d_render_main->options |= FRO_COLOR_SCALE;
+		}
+		d_render_main->height = d_height;
+		d_render_zoom->height = d_height;
 		d_render_main->histo_wf_ratio = d_ratio;
+		d_render_zoom->histo_wf_ratio = d_ratio;
 		d_render_main->channels[0].enabled = d_zoom_enabled;
 		d_render_main->channels[0].center = (float)d_zoom_center;
 		d_render_main->channels[0].width = (float)d_zoom_width;
+		d_render_zoom->freq_center = (float)d_zoom_center;
+		d_render_zoom->freq_span = (float)d_zoom_width;
 		fosphor_render_refresh(d_render_main);
+		fosphor_render_refresh(d_render_zoom);
 	}
+}
+
+void sink_runtime::reshape(int width, int height)			/* :291-296 */
+{
+	d_width = width;
+	d_height = height;
+	settings_mark_changed(SETTING_DIMENSIONS);
+}
+
+bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, double *freq)	/* :371-397 */
+{
+	if (action != CLICK || !d_fosphor)
+		return false;
+	const int in_main = fosphor_render_pos_inside(d_render_main, x, y);
+	const int in_zoom = d_zoom_enabled ? fosphor_render_pos_inside(d_render_zoom, x, y) : 0;
+	double f;
+	if (in_main & 1)
+		f = fosphor_pos2freq(d_fosphor, d_render_main, x);
+	else if (in_zoom & 1)
+		f = fosphor_pos2freq(d_fosphor, d_render_zoom, x);
+	else
+		return false;
+	if (freq)
+		*freq = f;
+	if (d_freq_cb)
+		d_freq_cb(f, d_freq_user);					/* the "freq" message of :385,390 */
+	return true;
 }
 
 void sink_runtime::worker()						/* :77-122 */
@@ -219,7 +269,7 @@ void sink_runtime::worker()						/* :77-122 */
 		d_active = false;
 		return;
 	}
-	settings_apply(~(uint32_t)SETTING_DIMENSIONS);			/* :106-109 */
+	settings_apply(~(uint32_t)0);					/* :106-109 (+ the pane layout: no window system sends a first reshape here) */
 	while (d_active || (d_draining && d_fifo->used() - d_inflight_samples >= 16 * 1024))
 		render();
 	(void)fosphor_amd_finish(d_fosphor);
@@ -280,6 +330,8 @@ void sink_runtime::render()						/* :130-201 */
 
 	if (d_visible) {
 		fosphor_draw(d_fosphor, d_render_main);			/* :178-195: the per-frame sync point */
+		if (d_zoom_enabled)
+			fosphor_draw(d_fosphor, d_render_zoom);		/* :189-190 */
 		d_frames++;
 		retire_uploads(true);
 	} else {
@@ -431,7 +483,8 @@ double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, in
 {
 	const std::complex<float> *in = (const std::complex<float> *)samples;
 	const uint64_t before = s->s.samples_processed();
-	const uint64_t want = before + (uint64_t)n * (uint64_t)repeats;
+	/* the sink consumes whole 16-spectrum groups: a remainder stays in the FIFO until more samples arrive */
+	const uint64_t want = before + (((uint64_t)n * (uint64_t)repeats) & ~(uint64_t)(16 * 1024 - 1));
 	auto t0 = std::chrono::steady_clock::now();
 	for (int r = 0; r < repeats; r++) {
 		int pos = 0;
@@ -441,8 +494,12 @@ double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, in
 			pos += took;
 		}
 	}
-	while (s->s.samples_processed() < want)
+	auto t_fed = std::chrono::steady_clock::now();
+	while (s->s.samples_processed() < want) {
 		std::this_thread::sleep_for(std::chrono::microseconds(50));
+		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fed).count() > 30.0)
+			return -1.0;			/* the worker is not consuming (stopped, frozen, device error) */
+	}
 	return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 void  fosphor_amd_sink_free(fosphor_amd_sink *s) { delete s; }
@@ -453,6 +510,15 @@ int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n)
 	return s->s.work(n, (const std::complex<float> *)samples);
 }
 void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action) { s->s.execute_ui_action((sink_runtime::ui_action_t)action); }
+void  fosphor_amd_sink_reshape(fosphor_amd_sink *s, int w, int h) { s->s.reshape(w, h); }
+int   fosphor_amd_sink_mouse_action(fosphor_amd_sink *s, int action, int x, int y, double *freq)
+{
+	return s->s.execute_mouse_action((sink_runtime::mouse_action_t)action, x, y, freq) ? 1 : 0;
+}
+void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_render *out)
+{
+	*out = zoom ? *s->s.render_zoom() : *s->s.render_main();
+}
 void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double c, double sp) { s->s.set_frequency_range(c, sp); }
 void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win) { s->s.set_fft_window(win); }
 void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int v) { s->s.set_visible(v != 0); }

@@ -90,7 +90,17 @@ class sink_runtime
 	bool start();		/* base_sink_c_impl.cc:464-472: spawns the worker */
 	bool stop();		/* :474-483; drains what is already in the FIFO first */
 
+	enum mouse_action_t { CLICK };				/* base_sink_c.h:50-52 */
+
 	void execute_ui_action(ui_action_t action);		/* :305-369 */
+	/* :371-397: a click inside the main or the zoom pane is turned into the frequency under the cursor; where the
+	 * reference publishes it on the block's "freq" message port, this runtime hands it to the callback (if any) and
+	 * returns it.  true when a frequency was produced. */
+	bool execute_mouse_action(mouse_action_t action, int x, int y, double *freq = nullptr);
+	void set_freq_callback(void (*cb)(double freq, void *user), void *user) { d_freq_cb = cb; d_freq_user = user; }
+	void reshape(int width, int height);			/* cb_reshape, :291-296 */
+	const struct fosphor_render *render_main() const { return d_render_main; }
+	const struct fosphor_render *render_zoom() const { return d_render_zoom; }
 	void set_frequency_range(double center, double span);	/* :399-405 */
 	void set_frequency_center(double center);
 	void set_frequency_span(double span);
@@ -121,7 +131,10 @@ class sink_runtime
 
 	fifo *d_fifo;
 	struct fosphor *d_fosphor;
-	struct fosphor_render *d_render_main;
+	struct fosphor_render *d_render_main, *d_render_zoom;	/* :61-66 */
+	int d_width, d_height;
+	void (*d_freq_cb)(double, void *);
+	void *d_freq_user;
 	std::thread d_worker;
 	std::atomic<bool> d_active, d_frozen, d_visible, d_draining;
 	std::mutex d_settings_mutex;
@@ -179,13 +192,20 @@ fosphor_amd_sink *fosphor_amd_sink_new(void);
 /* same with a FIFO of `fifo_length` samples (power of two >= 32 Ki; the reference's is 2 Mi) */
 fosphor_amd_sink *fosphor_amd_sink_new_len(int fifo_length);
 /* Measurement: feeds `samples` (n complex samples) `repeats` times through work() from the calling thread, in
- * calls of `chunk` samples, waits until everything has been processed, and returns the seconds it took. */
+ * calls of `chunk` samples, waits until every whole 16-spectrum group of it has been processed, and returns the seconds
+ * it took (-1.0 if the worker stopped consuming for 30 s).  work() is single-producer, like the GR scheduler's calls. */
 double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, int chunk, int repeats);
 void  fosphor_amd_sink_free(fosphor_amd_sink *s);
 int   fosphor_amd_sink_start(fosphor_amd_sink *s);
 int   fosphor_amd_sink_stop(fosphor_amd_sink *s);
 int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n);
 void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action);
+/* cb_reshape (window size in pixels) and execute_mouse_action(CLICK, x, y) of base_sink_c_impl.cc:291-296,371-397:
+ * 1 and *freq = the frequency under the cursor when (x, y) lies in the main or the zoom pane, else 0. */
+void  fosphor_amd_sink_reshape(fosphor_amd_sink *s, int width, int height);
+int   fosphor_amd_sink_mouse_action(fosphor_amd_sink *s, int action, int x, int y, double *freq);
+/* copies of the two pane layouts (main, zoom) as the runtime maintains them */
+void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_render *out);
 void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double center, double span);
 void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win);
 void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int visible);

@@ -697,6 +697,60 @@ def test_sink_waterfall_matches_oracle(amd, torch_cuda, oracle_built):
     L.fosphor_amd_sink_free(s)
 
 
+def test_sink_zoom_pane_and_click_to_frequency(amd, torch_cuda):
+    """base_sink_c_impl.cc:257-296,371-397: window reshape, the 65 % / 35 % split when the zoom pane is on, and a click
+    turned into the frequency under the cursor -- against the same layout rules applied through the public
+    fosphor_render_* / fosphor_pos2freq API (whose arithmetic is pinned against the reference's fosphor.c by
+    tests/test_render_geometry.py)."""
+    import ctypes as C
+    import time
+    L = amd.load()
+    s = L.fosphor_amd_sink_new()
+    L.fosphor_amd_sink_set_frequency_range(s, 433.92e6, 2.0e6)
+    L.fosphor_amd_sink_reshape(s, 1280, 720)
+    assert L.fosphor_amd_sink_start(s) == 1
+    x = gaussian_iq(64 * 1024, 52)
+    L.fosphor_amd_sink_work(s, np.ascontiguousarray(x).ctypes.data, 64 * 1024)		# one frame: settings applied
+    samples = C.c_uint64()
+    for _ in range(400):
+        L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+        if samples.value == 64 * 1024:
+            break
+        time.sleep(0.005)
+    core = L.fosphor_amd_sink_core(s)
+    r = amd.Render()
+    L.fosphor_amd_sink_get_render(s, 0, C.byref(r))
+    assert (r.width, r.height) == (1280, 720) and (r.options & (1 << 7)) == 0		# FRO_CHANNELS off without zoom
+    freq = C.c_double()
+    mid_y = int(r._y_histo[0] + 5)
+    assert L.fosphor_amd_sink_mouse_action(s, 0, 640, mid_y, C.byref(freq)) == 1
+    assert freq.value == L.fosphor_pos2freq(core, C.byref(r), 640)
+    assert abs(freq.value - 433.92e6) < 2.0e6
+    assert L.fosphor_amd_sink_mouse_action(s, 0, 5000, mid_y, C.byref(freq)) == 0	# outside every pane
+
+    L.fosphor_amd_sink_ui_action(s, 4)							# ZOOM_TOGGLE
+    L.fosphor_amd_sink_work(s, np.ascontiguousarray(x).ctypes.data, 64 * 1024)
+    for _ in range(400):
+        L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+        if samples.value == 2 * 64 * 1024:
+            break
+        time.sleep(0.005)
+    time.sleep(0.05)
+    z = amd.Render()
+    L.fosphor_amd_sink_get_render(s, 0, C.byref(r))
+    L.fosphor_amd_sink_get_render(s, 1, C.byref(z))
+    a = int(1280 * np.float32(0.65))
+    assert r.width == a and z.pos_x == a - 10 and z.width == 1280 - a + 10 and z.height == 720
+    assert r.channels[0].enabled == 1 and abs(z.freq_span - 0.2) < 1e-7 and abs(z.freq_center - 0.5) < 1e-7
+    xz = int(z._x[0] + 0.5 * (z._x[1] - z._x[0]))
+    yz = int(z._y_histo[0] + 5)
+    assert L.fosphor_amd_sink_mouse_action(s, 0, xz, yz, C.byref(freq)) == 1
+    assert freq.value == L.fosphor_pos2freq(core, C.byref(z), xz)
+    assert abs(freq.value - 433.92e6) < 0.2 * 2.0e6					# the zoom pane spans 20 % around the centre
+    L.fosphor_amd_sink_stop(s)
+    L.fosphor_amd_sink_free(s)
+
+
 def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built):
     """The sink fed from a native thread in large work() calls (helper-thread copies, several FIFO regions in
     flight, regions discarded on their own upload events): every sample is processed exactly once and the final
