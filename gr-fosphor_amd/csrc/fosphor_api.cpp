@@ -834,7 +834,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	const int did_prep = self->win_dirty || self->thr_dirty || self->state == ST_BOOTING;
 	const int wf_first_global = total > self->wf_rows ? total - self->wf_rows : 0;
 	int sub_b, n_sub, use_alt, used_alt = 0;
-	/* measurement only (results are wrong): FOSPHOR_AMD_DBG_SKIP bit 0 = no K1, bit 1 = no count / merge */
+	/* measurement only (results are wrong): FOSPHOR_AMD_DBG_SKIP bit 0 = no K1, bit 1 = no count / merge, bit 2 = no K3, bit 3 = no K2 */
 	static const int dbg_skip = [] { const char *e = getenv("FOSPHOR_AMD_DBG_SKIP"); return e ? atoi(e) : 0; }();
 
 	if (prepare(self))
@@ -928,7 +928,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		} else if (drain_h_sets(self, st2)) {
 			return -EIO;
 		}
-		if (run_count(self, nb, batch, tile, 0, 0, batch, st2, 1, hset))
+		if (!(dbg_skip & 8) && run_count(self, nb, batch, tile, 0, 0, batch, st2, 1, hset))
 			return -EIO;
 		if (self->overlap) {
 			HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
@@ -938,7 +938,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 			HIP_TRY(hipEventRecord(self->ev_k2_done[hset], st2), "record K2 done");
 			HIP_TRY(hipStreamWaitEvent(st3, self->ev_k2_done[hset], 0), "K3 waits for K2");
 		}
-		if (run_merge(self, nb, batch, 0, st3, 1, hset))
+		if (!(dbg_skip & 4) && run_merge(self, nb, batch, 0, st3, 1, hset))
 			return -EIO;
 		if (three) {
 			HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
