@@ -195,7 +195,7 @@ def main():
                 if rv:
                     raise RuntimeError("process_device -> %d" % rv)
             else:
-                sf.frame(view, F * spb * world, overlap=True, wait_producer=False)
+                sf.frame(view, F * spb * world, overlap=True, wait_producer=False, overlap_ratio=over)
         if sf is not None:
             sf.flush()
 

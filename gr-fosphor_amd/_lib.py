@@ -84,6 +84,7 @@ SIGNATURES = {
     "fosphor_amd_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "fosphor_amd_bin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "fosphor_amd_accumulate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "fosphor_amd_accumulate_device_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_set_partial_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "fosphor_amd_get_partials": (C.c_int, [C.c_void_p, C.POINTER(Partials)]),
     "fosphor_amd_merge": (C.c_int, [C.c_void_p, C.c_int]),

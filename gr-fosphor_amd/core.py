@@ -88,7 +88,9 @@ class Fosphor:
     def finish(self):
         return self.L.fosphor_amd_finish(self.h)
 
-    def accumulate_device(self, d_samples, n_local, t_offset, total_batch):
+    def accumulate_device(self, d_samples, n_local, t_offset, total_batch, overlap=1):
+        if overlap > 1:
+            return self.L.fosphor_amd_accumulate_device_overlap(self.h, _ptr(d_samples), n_local, t_offset, total_batch, overlap)
         return self.L.fosphor_amd_accumulate_device(self.h, _ptr(d_samples), n_local, t_offset, total_batch)
 
     def merge(self, total_batch):

@@ -1171,8 +1171,7 @@ extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_
 /* Multi-GPU split                                                          */
 /* ------------------------------------------------------------------------ */
 
-extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
-                                             int n_local, int t_offset, int total_batch)
+static int accumulate(struct fosphor *self, const void *d_samples, int n_local, int t_offset, int total_batch, int hop)
 {
 	K1Params k1;
 	int tile, wf_first, set;
@@ -1231,8 +1230,8 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 				if (wf_first < 0) wf_first = 0;
 				stores_rows = wf_first < sub_total;
 				if (!stores_rows) wf_first = sub_total;
-				fill_k1(self, &k1, (const char *)d_samples + (size_t)t0 * self->n * sample_bytes, sub_total, tile,
-				        (self->wf_pos + t_offset + t0) & (self->wf_rows - 1), wf_first);
+				fill_k1(self, &k1, (const char *)d_samples + (size_t)t0 * (hop ? hop : self->n) * sample_bytes, sub_total, tile,
+				        (self->wf_pos + t_offset + t0) & (self->wf_rows - 1), wf_first, hop);
 				if (stores_rows && wf_enter(self, ks))
 					return -EIO;
 				prof_begin(self, 0, ks);
@@ -1298,7 +1297,7 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	/* global spectrum index tau = t_offset + t stores its row iff tau >= total_batch - wf_rows */
 	wf_first = total_batch - self->wf_rows - t_offset;
 	if (wf_first < 0) wf_first = 0;
-	fill_k1(self, &k1, d_samples, n_local, tile, (self->wf_pos + t_offset) & (self->wf_rows - 1), wf_first);
+	fill_k1(self, &k1, d_samples, n_local, tile, (self->wf_pos + t_offset) & (self->wf_rows - 1), wf_first, hop);
 	if (wf_enter(self, self->stream))
 		return -EIO;
 	prof_begin(self, 0, self->stream);
@@ -1327,6 +1326,22 @@ extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d
 	return 0;
 error:
 	return -EIO;
+}
+
+extern "C" int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
+                                             int n_local, int t_offset, int total_batch)
+{
+	return accumulate(self, d_samples, n_local, t_offset, total_batch, 0);
+}
+
+/* the same with overlap_cc fused into the read (see fosphor_amd_process_device_overlap): d_samples is this rank's part
+ * of the UNEXPANDED stream, (n_local - 1) * N / overlap + N samples starting at the first sample of its first spectrum */
+extern "C" int fosphor_amd_accumulate_device_overlap(struct fosphor *self, const void *d_samples,
+                                                     int n_local, int t_offset, int total_batch, int overlap)
+{
+	if (!self || overlap < 1 || overlap > self->n || (self->n % overlap))
+		return -EINVAL;
+	return accumulate(self, d_samples, n_local, t_offset, total_batch, self->n / overlap);
 }
 
 extern "C" int fosphor_amd_set_partial_slot(struct fosphor *self, int slot)

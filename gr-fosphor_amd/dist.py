@@ -175,9 +175,10 @@ class ShardedFosphor:
             raise RuntimeError("merge -> %d" % rv)
         self.pending = None
 
-    def frame(self, d_samples_local, total_batch, overlap=False, wait_producer=True):
+    def frame(self, d_samples_local, total_batch, overlap=False, wait_producer=True, overlap_ratio=1):
         """wait_producer=False: the caller guarantees d_samples_local is complete (saves the event
-        record + wait between the caller's stream and the FFT stream, two queue packets per frame)."""
+        record + wait between the caller's stream and the FFT stream, two queue packets per frame).
+        overlap_ratio > 1: d_samples_local is this rank's part of the unexpanded stream (overlap_cc fused into the read)."""
         torch = self.torch
         off, n = shard_range(total_batch, self.rank, self.world)
         if wait_producer:
@@ -187,7 +188,7 @@ class ShardedFosphor:
             self.k += 1
             with torch.cuda.stream(self.stream):
                 self.f.set_partial_slot(slot)
-                rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)	# K1 here, K2 on stream_b
+                rv = self.f.accumulate_device(d_samples_local, n, off, total_batch, overlap_ratio)	# K1 here, K2 on stream_b
                 if rv:
                     raise RuntimeError("accumulate_device -> %d" % rv)
             with torch.cuda.stream(self.stream_b):
@@ -204,7 +205,7 @@ class ShardedFosphor:
         # native transport (or a single rank without exchange): three C calls, all asynchronous; K2, the
         # exchange and K3 follow each other on the library's count/merge stream while `stream` is already free
         # for the next frame's K1
-        rv = self.f.accumulate_device(d_samples_local, n, off, total_batch)
+        rv = self.f.accumulate_device(d_samples_local, n, off, total_batch, overlap_ratio)
         if rv:
             raise RuntimeError("accumulate_device -> %d" % rv)
         if self.comm is not None:

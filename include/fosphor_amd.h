@@ -120,6 +120,12 @@ int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_bin, void *
 int fosphor_amd_accumulate_device(struct fosphor *self, const void *d_samples,
                                   int n_local, int t_offset, int total_batch);
 
+/* The same with the overlap of overlap_cc fused into the read (fosphor_amd_process_device_overlap): d_samples is this
+ * rank's part of the UNEXPANDED stream, (n_local - 1) * N / overlap + N samples from the first sample of its first
+ * spectrum. */
+int fosphor_amd_accumulate_device_overlap(struct fosphor *self, const void *d_samples,
+                                          int n_local, int t_offset, int total_batch, int overlap);
+
 /* Select which of the instance's partial-array slots (0 .. max_batches - 1) the next
  * accumulate / get_partials / merge use.  Two slots let the all-reduce of frame k overlap the
  * FFT of frame k+1. */

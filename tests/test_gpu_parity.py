@@ -625,6 +625,48 @@ def test_fused_overlap_equals_materialised_stream(amd, torch_cuda, oracle_built,
     f.close(); g.close()
 
 
+def test_sharded_frame_with_fused_overlap(amd, torch_cuda, oracle_built):
+    """fosphor_amd_accumulate_device_overlap: two time shards of one 256-spectrum frame, each reading its part of the
+    UNEXPANDED stream (overlap 2), combined the way the exchange would: the counts, and after the merge the state, of
+    the single launch over the materialised stream (oracle)."""
+    torch = torch_cuda
+    from gr_fosphor_amd.dist import combine_partials_numpy, wrap_device_array
+    n, over, B = 1024, 2, 256
+    hop = n // over
+    x = add_tone(gaussian_iq((B - 1) * hop + n, 471), 0.1, 0.171)
+    expanded = overlap_cc_reference(x, n, over)[:B * n]
+    o = Oracle()
+    assert o.process(expanded, strict=False, nthreads=8) == 0
+    d = torch.from_numpy(x).cuda()
+    parts = []
+    ranks = []
+    for r in range(2):
+        f = amd.Fosphor(max_spectra=B)
+        off = r * (B // 2)
+        assert f.accumulate_device(d[off * hop:], B // 2, off, B, overlap=over) == 0
+        assert f.finish() >= 0
+        p = f.partials()
+        parts.append((wrap_device_array(p.d_hc, (p.n_hc,), torch.int32).cpu().numpy().view(np.uint32),
+                      wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32).cpu().numpy(),
+                      wrap_device_array(p.d_max, (p.n_cols,), torch.float32).cpu().numpy()))
+        ranks.append(f)
+    hc, live, vmax = combine_partials_numpy(parts)
+    assert np.array_equal(hc.reshape(128, 1024), o.hitcount.T), "sharded overlap counts"
+    f = ranks[0]
+    p = f.partials()
+    wrap_device_array(p.d_hc, (p.n_hc,), torch.int32).copy_(torch.from_numpy(hc.view(np.int32)))
+    wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32).copy_(torch.from_numpy(live))
+    wrap_device_array(p.d_max, (p.n_cols,), torch.float32).copy_(torch.from_numpy(vmax))
+    torch.cuda.synchronize()
+    assert f.merge(B) == 0
+    assert_hist_close(f.histogram, o.histogram, "sharded overlap histogram")
+    assert_close(f.spectrum[0, :, 1], o.spectrum[0, :, 1], "sharded overlap live")
+    assert_close(f.spectrum[1, :, 1], o.spectrum[1, :, 1], "sharded overlap max-hold")
+    assert f.accumulate_device(d, B, 0, B, overlap=3) == -errno.EINVAL
+    for q in ranks:
+        q.close()
+
+
 def test_sink_runtime_streams_through_fifo(amd, torch_cuda, oracle_built):
     """N2: the GNU-Radio-free sink (work() -> pinned fifo -> worker thread -> fosphor_process ->
     fosphor_draw), fed like the GR scheduler feeds base_sink_c_impl::work.  Batch boundaries depend
