@@ -625,6 +625,58 @@ def test_fused_overlap_equals_materialised_stream(amd, torch_cuda, oracle_built,
     f.close(); g.close()
 
 
+@pytest.mark.parametrize("seed,relaxed", [(1, False), (2, True), (3, False), (4, True)])
+def test_random_call_sequences(amd, torch_cuda, oracle_built, monkeypatch, seed, relaxed):
+    """Random mixes of every entry point -- fosphor_process, device-resident calls of 1..12 batches (cut into sub-launches
+    of 64 spectra here, K1s alternating between the two FFT streams, waterfall rings flipping whenever a call rewrites
+    the 64-row ring), fused-overlap calls, sharded frames (accumulate + merge), draws in between -- against the oracle fed
+    the same spectra in the same order."""
+    torch = torch_cuda
+    monkeypatch.setenv("FOSPHOR_AMD_SUB_LOG2", "16")
+    rng = np.random.default_rng(9000 + seed)
+    n = 1024
+    f = amd.Fosphor(n_bins=256, wf_rows=64, max_spectra=2048, max_batches=16)
+    if relaxed:
+        assert f.set_input_ordering(False) == 0
+    o = Oracle(n_bins=256, wf_rows=64)
+    keep = []
+    t0 = 0
+    for step in range(14):
+        kind = rng.integers(0, 5)
+        if kind == 0:					# reference entry point, host samples
+            b = int(rng.choice([16, 32, 64, 160]))
+            x = add_tone(gaussian_iq(b * n, 9100 + 20 * seed + step), 0.1, 0.03 * (step + 1), t0=t0)
+            assert f.process(x) == 0 and o.process(x, nthreads=8) == 0
+        elif kind in (1, 2):				# device-resident call, several batches
+            nb, b = int(rng.integers(1, 13)), int(rng.choice([16, 48, 128]))
+            x = add_tone(gaussian_iq(nb * b * n, 9100 + 20 * seed + step), 0.1, 0.03 * (step + 1), t0=t0)
+            keep.append(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+            assert f.process_device(keep[-1], nb, b) == 0
+            for k in range(nb):
+                assert o.process(x[k * b * n:(k + 1) * b * n], nthreads=8) == 0
+        elif kind == 3:					# overlap_cc fused into the read
+            nb, b, over = int(rng.integers(1, 5)), 64, int(rng.choice([2, 4]))
+            hop = n // over
+            x = add_tone(gaussian_iq((nb * b - 1) * hop + n, 9100 + 20 * seed + step), 0.1, 0.021 * (step + 1), t0=t0)
+            keep.append(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+            assert f.process_device_overlap(keep[-1], nb, b, over) == 0
+            ex = overlap_cc_reference(x, n, over)
+            for k in range(nb):
+                assert o.process(ex[k * b * n:(k + 1) * b * n], nthreads=8) == 0
+        else:						# a sharded frame held by one rank
+            b = int(rng.choice([64, 256, 2048]))
+            x = add_tone(gaussian_iq(b * n, 9100 + 20 * seed + step), 0.1, 0.017 * (step + 1), t0=t0)
+            keep.append(torch.from_numpy(x).cuda()); torch.cuda.synchronize()
+            assert f.accumulate_device(keep[-1], b, 0, b) == 0 and f.merge(b) == 0
+            assert o.process(x, strict=False, nthreads=8) == 0
+        t0 += 4096
+        if rng.integers(0, 3) == 0:
+            assert f.draw() == o.waterfall_pos
+            compare_state(f, o, "seed %d step %d (kind %d)" % (seed, step, kind))
+    compare_state(f, o, "seed %d, end" % seed)
+    f.close()
+
+
 def test_sharded_frame_with_fused_overlap(amd, torch_cuda, oracle_built):
     """fosphor_amd_accumulate_device_overlap: two time shards of one 256-spectrum frame, each reading its part of the
     UNEXPANDED stream (overlap 2), combined the way the exchange would: the counts, and after the merge the state, of
