@@ -284,6 +284,12 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #ifndef K1_PRIO
 #define K1_PRIO 0
 #endif
+#ifndef K1_NT_BINS
+#define K1_NT_BINS 0			/* non-temporal stores for the bin indices (measured: see DESIGN.md) */
+#endif
+#ifndef K2_NT_LOAD
+#define K2_NT_LOAD 0			/* non-temporal loads of the bin indices in K2 */
+#endif
 #ifndef K1_UNIFORM
 #define K1_UNIFORM 1			/* wave-uniform control values in SGPRs, in-place Horner, one branch for the row stores */
 #endif
@@ -625,7 +631,11 @@ void k1_fft_bin(const K1Params p)
 		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
 #pragma unroll
 		for (int m = 0; m < 16; m++)
+#if K1_NT_BINS
+			__builtin_nontemporal_store(pack[m], &dst[64 * m]);
+#else
 			dst[64 * m] = pack[m];
+#endif
 	}
 
 	/* leave the log2 domain: pwr = log10|X| = l2 * log10(2)/2; an untouched max is exactly -1000 */
@@ -2235,7 +2245,11 @@ void k2_count(const K2Params p)
 			uint32_t v[K2_INFLIGHT];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++)
+#if K2_NT_LOAD
+				v[u] = __builtin_nontemporal_load(&src[(q + NW * u) * n + lane]);
+#else
 				v[u] = src[(q + NW * u) * n + lane];
+#endif
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++) {
 				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
