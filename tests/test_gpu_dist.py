@@ -138,3 +138,21 @@ def test_native_rccl_exchange_single_rank(tmp_path, sliced):
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300)
     assert p.returncode == 0 and "native ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_c_program_native_exchange(tmp_path):
+    """tests/c/exchange_test.c: a plain C host (no Python, no PyTorch in the process) links libfosphor_amd.so, creates the
+    library's RCCL communicator and runs accumulate -> fosphor_amd_exchange -> merge for three frames; counts and histogram
+    must equal the single-launch path of the same ABI."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    exe = tmp_path / "exchange_test"
+    libdir = os.path.join(ROOT, "gr-fosphor_amd")
+    cmd = ["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "exchange_test.c"),
+           "-o", str(exe), "-L", libdir, "-lfosphor_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert b.returncode == 0, b.stdout
+    p = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0 and "c exchange ok" in p.stdout, p.stdout[-2000:]
