@@ -112,6 +112,9 @@ def cpu_baseline(bins, seconds):
 
 def main():
     args = parse()
+    # The library's two FFT streams must not share a hardware queue with each other or with RCCL's streams
+    # (HIP maps streams onto 4 queues by default; DESIGN.md section 5 "Hardware queues"): neutral at N=1 (measured).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
 

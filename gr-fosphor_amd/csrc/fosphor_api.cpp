@@ -39,7 +39,8 @@ using namespace fosphor_amd;
 enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 
 static const int kMaxN = 65536;
-static const int kSets = 3;		/* intermediate (bin index / partial) sets in rotation */
+static const int kSets = 5;		/* intermediate (bin index / partial) sets in rotation */
+static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams */
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
@@ -82,12 +83,16 @@ struct fosphor
 	uint32_t *d_bins;			/* current set */
 	float2   *d_partial;
 	int       pp;
-	hipStream_t stream_alt;			/* K1 of every other sub-launch of a device-resident call: consecutive K1s overlap at their edges */
+	hipStream_t k1_streams[kMaxK1Streams];	/* [0] = `stream`; the K1s of consecutive sub-launches of a device-resident call rotate over
+						 * n_k1_streams of them: the next K1s are already queued when work-groups of the current one exit */
+	int       n_sets;			/* FOSPHOR_AMD_SETS (default 3): intermediate sets in use, <= kSets */
+	int       n_k1_streams;			/* FOSPHOR_AMD_K1_STREAMS (default 2) */
+	hipEvent_t ev_k1s_done[kMaxK1Streams];
 	int       alt;				/* FOSPHOR_AMD_ALT=0 keeps every K1 on `stream` */
 	int       k23;				/* FOSPHOR_AMD_K23=1: counts and state update fused (k23_strip) */
 	int       k1_seq;
 	int       relaxed;			/* fosphor_amd_set_input_ordering(self, 0) */
-	hipEvent_t ev_in, ev_alt_done;
+	hipEvent_t ev_in;
 	long long sub_samples;			/* samples per sub-launch of a device-resident call */
 	hipStream_t stream2;			/* K2 (and K3 unless pipe3) of the multi-batch path */
 	hipStream_t stream3;			/* K3 of the multi-batch path: K3 of launch i beside K2 of launch i+1 */
@@ -237,8 +242,10 @@ extern "C" void fosphor_release(struct fosphor *self)
 	for (int i = 0; i < 2; i++)
 		if (self->ev_wf[i]) (void)hipEventDestroy(self->ev_wf[i]);
 	if (self->ev_in) (void)hipEventDestroy(self->ev_in);
-	if (self->ev_alt_done) (void)hipEventDestroy(self->ev_alt_done);
-	if (self->stream_alt) { (void)hipStreamSynchronize(self->stream_alt); (void)hipStreamDestroy(self->stream_alt); }
+	for (int i = 1; i < kMaxK1Streams; i++) {
+		if (self->k1_streams[i]) { (void)hipStreamSynchronize(self->k1_streams[i]); (void)hipStreamDestroy(self->k1_streams[i]); }
+		if (self->ev_k1s_done[i]) (void)hipEventDestroy(self->ev_k1s_done[i]);
+	}
 	for (int i = 0; i < kSets; i++) {
 		(void)hipFree(self->d_bins_pp[i]); (void)hipFree(self->d_partial_pp[i]);
 		if (self->ev_k1_done[i]) (void)hipEventDestroy(self->ev_k1_done[i]);
@@ -354,8 +361,17 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_wf[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipEventCreateWithFlags(&self->ev_in, dep_event_flags()), "create event");
-	HIP_TRY(hipEventCreateWithFlags(&self->ev_alt_done, dep_event_flags()), "create event");
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream_alt, hipStreamNonBlocking), "hipStreamCreate (second FFT stream)");
+	/* Only the streams in use are created: the runtime spreads streams over a few hardware queues (4 unless
+	 * GPU_MAX_HW_QUEUES says otherwise) and two streams that share one do not overlap. */
+	{
+		const char *e = getenv("FOSPHOR_AMD_K1_STREAMS");
+		self->n_k1_streams = (e && atoi(e) >= 1 && atoi(e) <= kMaxK1Streams) ? atoi(e) : 2;
+	}
+	self->k1_streams[0] = self->stream;
+	for (int i = 1; i < self->n_k1_streams; i++) {
+		HIP_TRY(hipStreamCreateWithFlags(&self->k1_streams[i], hipStreamNonBlocking), "hipStreamCreate (FFT stream)");
+		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1s_done[i], dep_event_flags()), "create event");
+	}
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
 	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * self->n), "alloc spectrum");
 	for (int i = 0; i < kSets; i++) {
@@ -390,6 +406,10 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->pipe3 = (e && *e == '1');
 		e = getenv("FOSPHOR_AMD_ALT");
 		self->alt = !(e && *e == '0');
+		e = getenv("FOSPHOR_AMD_SETS");
+		self->n_sets = (e && atoi(e) >= 2 && atoi(e) <= kSets) ? atoi(e) : 3;
+		if (self->n_k1_streams == 1)
+			self->alt = 0;
 		/* fused count + merge (k23_strip): 9 % fewer bytes, but its batches are a serial chain (1.6 us each) that
 		 * today costs more than the bytes it saves -- opt-in until that chain is shorter */
 		e = getenv("FOSPHOR_AMD_K23");
@@ -517,7 +537,8 @@ static int sync_all(struct fosphor *self)
 {
 	int rv = 0;
 	if (self->stream  && hipStreamSynchronize(self->stream)  != hipSuccess) rv = -EIO;
-	if (self->stream_alt && hipStreamSynchronize(self->stream_alt) != hipSuccess) rv = -EIO;
+	for (int i = 1; i < kMaxK1Streams; i++)
+		if (self->k1_streams[i] && hipStreamSynchronize(self->k1_streams[i]) != hipSuccess) rv = -EIO;
 	if (self->stream2 && hipStreamSynchronize(self->stream2) != hipSuccess) rv = -EIO;
 	if (self->stream3 && hipStreamSynchronize(self->stream3) != hipSuccess) rv = -EIO;
 	return rv;
@@ -800,6 +821,27 @@ error:
 	return -EIO;
 }
 
+/* the other FFT streams see what the caller (and prepare()) queued on `stream` ... */
+static int k1_streams_fork(struct fosphor *self)
+{
+	if (hipEventRecord(self->ev_in, self->stream) != hipSuccess)
+		return -EIO;
+	for (int i = 1; i < self->n_k1_streams; i++)
+		if (hipStreamWaitEvent(self->k1_streams[i], self->ev_in, 0) != hipSuccess)
+			return -EIO;
+	return 0;
+}
+
+/* ... and what the caller queues on `stream` next follows every K1 queued on them */
+static int k1_streams_join(struct fosphor *self)
+{
+	for (int i = 1; i < self->n_k1_streams; i++)
+		if (hipEventRecord(self->ev_k1s_done[i], self->k1_streams[i]) != hipSuccess ||
+		    hipStreamWaitEvent(self->stream, self->ev_k1s_done[i], 0) != hipSuccess)
+			return -EIO;
+	return 0;
+}
+
 /* Waterfall ring ownership between K1s that may run on different streams: a K1 that stores rows into ring b
  * follows the previous K1 that did. */
 static int wf_enter(struct fosphor *self, hipStream_t ks)
@@ -843,7 +885,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	/* Sub-launches.  A call is cut into pieces of about sub_samples samples (64 reference batches): the
 	 * bin-index / partial intermediates of a piece stay small enough to be consumed by K2 out of the Infinity
 	 * Cache, and the pipeline below overlaps K2/K3 of piece j with K1 of piece j+1 INSIDE one call.
-	 *   K1 (j)   on `stream` / `stream_alt` alternately: K1 of piece j+1 is dispatched while K1 of piece j
+	 *   K1 (j)   on `stream` and the other FFT streams in rotation: K1 of piece j+1 is dispatched while K1 of piece j
 	 *            drains, so no CU idles between them (kernel tail, dispatch gap and prologue overlap);
 	 *   K2 (j)   on stream2 once K1 (j) has finished; K3 (j) follows it there, so the persistent state sees the
 	 *            batches in order.
@@ -860,9 +902,8 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	if (use_alt && total >= self->wf_rows)
 		self->wf_cur ^= 1;
 	if (use_alt && (did_prep || !self->relaxed)) {
-		/* the second FFT stream sees what the caller (and prepare()) queued on `stream` */
-		HIP_TRY(hipEventRecord(self->ev_in, self->stream), "record input ready");
-		HIP_TRY(hipStreamWaitEvent(self->stream_alt, self->ev_in, 0), "second FFT stream waits for the input");
+		if (k1_streams_fork(self))
+			return -EIO;
 	}
 
 	for (int b0 = 0; b0 < n_batches; b0 += sub_b) {
@@ -873,12 +914,12 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		K1Params k1;
 		int set, hset = 0, wf_first, stores_rows;
 
-		if (use_alt && (self->k1_seq++ & 1)) {
-			ks = self->stream_alt;
+		if (use_alt) {
+			ks = self->k1_streams[self->k1_seq++ % self->n_k1_streams];
 			used_alt = 1;
 		}
 		set = self->pp;
-		self->pp = (self->pp + 1) % kSets;
+		self->pp = (self->pp + 1) % self->n_sets;
 		self->d_bins = self->d_bins_pp[set];
 		self->d_partial = self->d_partial_pp[set];
 		if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
@@ -948,8 +989,8 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	}
 	if (used_alt && !self->relaxed) {
 		/* what the caller queues on `stream` next (e.g. refilling the sample buffer) follows every K1 */
-		HIP_TRY(hipEventRecord(self->ev_alt_done, self->stream_alt), "record second FFT stream");
-		HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_alt_done, 0), "stream waits for the second FFT stream");
+		if (k1_streams_join(self))
+			return -EIO;
 	}
 	self->last_hc16 = (batch <= 1024 || count_one_chunk(self, batch, self->last_batches));
 
@@ -1204,8 +1245,8 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 			if (drain_h_sets(self, st2))
 				return -EIO;
 			if (use_alt && (did_prep || !self->relaxed)) {
-				HIP_TRY(hipEventRecord(self->ev_in, self->stream), "record input ready");
-				HIP_TRY(hipStreamWaitEvent(self->stream_alt, self->ev_in, 0), "second FFT stream waits for the input");
+				if (k1_streams_fork(self))
+					return -EIO;
 			}
 			for (int c0 = 0; c0 < cpb; c0 += sub_c) {
 				const int nc = (cpb - c0 < sub_c) ? cpb - c0 : sub_c;
@@ -1214,12 +1255,12 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				K2Params k2;
 				int stores_rows;
 
-				if (use_alt && (self->k1_seq++ & 1)) {
-					ks = self->stream_alt;
+				if (use_alt) {
+					ks = self->k1_streams[self->k1_seq++ % self->n_k1_streams];
 					used_alt = 1;
 				}
 				set = self->pp;
-				self->pp = (self->pp + 1) % kSets;
+				self->pp = (self->pp + 1) % self->n_sets;
 				self->d_bins = self->d_bins_pp[set];
 				self->d_partial = self->d_partial_pp[set];
 				if (self->overlap && self->set_used[set])
@@ -1275,8 +1316,8 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				HIP_TRY(launch_k2c(k2b, st2), "launch chunk sum");
 			}
 			if (used_alt && !self->relaxed) {
-				HIP_TRY(hipEventRecord(self->ev_alt_done, self->stream_alt), "record second FFT stream");
-				HIP_TRY(hipStreamWaitEvent(self->stream, self->ev_alt_done, 0), "stream waits for the second FFT stream");
+				if (k1_streams_join(self))
+					return -EIO;
 			}
 			self->wf_pos = (self->wf_pos + total_batch) & (self->wf_rows - 1);
 			self->state = ST_PENDING;
@@ -1287,7 +1328,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 	/* one K1 launch: same two-stream pipeline as run(): K1 on `stream`, K2 (and later the exchange and
 	 * fosphor_amd_merge's K3) on `stream2`, intermediates rotating between the sets */
 	set = self->pp;
-	self->pp = (self->pp + 1) % kSets;
+	self->pp = (self->pp + 1) % self->n_sets;
 	self->d_bins = self->d_bins_pp[set];
 	self->d_partial = self->d_partial_pp[set];
 	if (self->overlap && self->set_used[set])
@@ -1656,10 +1697,7 @@ extern "C" int fosphor_amd_wait_input(struct fosphor *self)
 {
 	if (!self)
 		return -EINVAL;
-	if (hipEventRecord(self->ev_alt_done, self->stream_alt) != hipSuccess ||
-	    hipStreamWaitEvent(self->stream, self->ev_alt_done, 0) != hipSuccess)
-		return -EIO;
-	return 0;
+	return k1_streams_join(self);
 }
 
 /* The stream K2 / K3 run on: a second stream when the two-stream pipeline is on, else the main

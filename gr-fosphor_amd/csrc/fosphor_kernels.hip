@@ -580,7 +580,10 @@ void k1_fft_bin(const K1Params p)
 				amb = amb > ab ? amb : ab;			/* v_max_u32: NaN / inf propagate */
 				pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
 			}
-			if (amb > __float_as_uint(bk.amb)) {
+#ifndef K1_DBG_NO_EXACT
+#define K1_DBG_NO_EXACT 0		/* measurement only: 1 drops the exact path (wrong bins on near-ties) */
+#endif
+			if (!K1_DBG_NO_EXACT && amb > __float_as_uint(bk.amb)) {
 				/* rare (a few % of spectra have one such sample): find the samples, decide them
 				 * against the exact thresholds, patch their bin byte and log-power */
 #pragma unroll
