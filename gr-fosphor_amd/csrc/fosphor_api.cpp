@@ -43,6 +43,7 @@ static const int kSets = 5;		/* intermediate (bin index / partial) sets in rotat
 static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams */
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
+static const size_t kLazyExportBytes = (size_t)32 << 20;	/* hit-count views this large are made on demand (fosphor_amd_get_buffers) */
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
 
 struct fosphor
@@ -110,6 +111,7 @@ struct fosphor
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
+	const uint16_t *export_src;		/* ... or made from these slabs when fosphor_amd_get_buffers asks */
 	uint16_t *d_slab16;			/* per-chunk packed 16-bit count slabs of batches longer than 1024 spectra / of a shard */
 	int       slab_chunks;			/* capacity of d_slab16 in 1024-spectrum chunks */
 	int       last_hc16;
@@ -123,6 +125,9 @@ struct fosphor
 	float     rise_t0r, rise_t0d;
 	int       slot;				/* partial-array slot used by accumulate/merge */
 	float2   *d_scratch;			/* N = 65536: [max_spectra][N] spectrum between the two FFT stages */
+	int       k1h_fused;			/* N = 65536: both stages in one kernel, the intermediate in the XCDs' L2 (FOSPHOR_AMD_K1H_FUSED=0: two kernels) */
+	uint32_t *d_k1h_sync;			/* its cluster counters */
+	uint32_t *h_k1h_err;			/* ... and its error word (host memory the kernel writes: work-groups of a cluster on different XCDs) */
 
 	/* host->device staging for fosphor_process (pinned ring of 2) */
 	float2   *h_stage[2];
@@ -264,6 +269,8 @@ extern "C" void fosphor_release(struct fosphor *self)
 	(void)hipFree(self->d_rise);
 	(void)hipFree(self->d_palette);
 	(void)hipFree(self->d_scratch);
+	(void)hipFree(self->d_k1h_sync);
+	if (self->h_k1h_err) (void)hipHostFree(self->h_k1h_err);
 	(void)hipFree(self->d_dbg);
 	if (self->h_rise) (void)hipHostFree(self->h_rise);
 	for (int i = 0; i < 2; i++) {
@@ -382,8 +389,16 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
-	if (self->log2n == 16)
-		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)self->max_spectra * self->n), "alloc stage scratch");
+	if (self->log2n == 16) {
+		const char *e = getenv("FOSPHOR_AMD_K1H_FUSED");
+		self->k1h_fused = !(e && *e == '0');
+		/* two kernels: the whole launch's intermediate; fused: 512 KiB per cluster (kept at 64 clusters' worth) */
+		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)(self->max_spectra < 64 ? 64 : self->max_spectra) * self->n), "alloc stage scratch");
+		HIP_TRY(hipMalloc((void **)&self->d_k1h_sync, sizeof(uint32_t) * 64 * 64), "alloc cluster counters");
+		HIP_TRY(hipMemset(self->d_k1h_sync, 0, sizeof(uint32_t) * 64 * 64), "clear cluster counters");
+		HIP_TRY(hipHostMalloc((void **)&self->h_k1h_err, 64, hipHostMallocMapped), "alloc error word");
+		self->h_k1h_err[0] = 0;
+	}
 	/* host staging slot: the reference's cap of 1024 spectra per call (cl.c:885), or this instance's */
 	self->stage_samples = (size_t)self->n * (self->max_spectra < 1024 ? self->max_spectra : 1024);
 	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
@@ -608,6 +623,13 @@ static int pick_tile(const struct fosphor *self, int total, int batch)
 	const int v = e ? atoi(e) : 0;
 	if (v >= 4 && v <= 128 && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
 		return v;
+	if (self->log2n == 16 && self->k1h_fused) {
+		/* a cluster owns whole tiles: the largest tile that still gives each of the 32 clusters one */
+		for (int t = 64; t >= 8; t >>= 1)
+			if (batch % t == 0 && total / t >= 32)
+				return t;
+		return 4;
+	}
 	if (self->log2n != 10 || self->bins16) {
 		/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
 		if (total / 16 >= 2048) return 16;
@@ -662,6 +684,12 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->w = 1.0f - self->alpha;		/* display.cl:99 */
 	k1->variant = (self->log2n == 10 && !self->bins16) ? self->k1_variant : (self->log2n == 16 ? 4 : 3);
 	k1->scratch = self->d_scratch;
+	k1->sync = (self->log2n == 16 && self->k1h_fused) ? self->d_k1h_sync : NULL;
+	k1->sync_err = self->h_k1h_err;
+	{
+		static const int dbg = [] { const char *e = getenv("FOSPHOR_AMD_DBG_K1H"); return e ? atoi(e) : 0; }();
+		k1->dbg_k1h = dbg;
+	}
 	k1->iq_half = self->iq_half;
 	if ((k1->variant == 1 || k1->variant >= 5) && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
@@ -778,6 +806,13 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.hc16 = (use16 && (batch <= 1024 || one_chunk) && have_table)
 	          ? (const uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	k3.hc_export = self->d_hc_export;
+	if (k3.hc16 && cells * sizeof(uint32_t) >= kLazyExportBytes) {
+		/* a view as large as the state itself (N = 65536: 128 MiB per batch) is made when somebody asks for it */
+		k3.hc_export = NULL;
+		self->export_src = k3.hc16 + (size_t)(n_batches - 1) * cells;
+	} else {
+		self->export_src = NULL;
+	}
 	k3.live_sum = self->d_live_sum + (size_t)lslot * self->n;
 	k3.vmax = self->d_vmax + (size_t)lslot * self->n;
 	k3.hist = self->d_hist; k3.spectrum = self->d_spectrum;
@@ -808,6 +843,7 @@ static int run_k23(struct fosphor *self, int n_batches, int batch, int tile, hip
 	k.bins = self->d_bins; k.partial = self->d_partial;
 	k.hist = self->d_hist; k.spectrum = self->d_spectrum;
 	k.hc_export = self->d_hc_export;
+	self->export_src = NULL;
 	k.rise = self->d_rise;
 	k.n = self->n; k.n_bins = self->n_bins; k.n_batches = n_batches; k.batch = batch; k.tile = tile;
 	k.log2_w = (float)log2((double)(1.0f - self->alpha));
@@ -896,6 +932,8 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	n_sub = (n_batches + sub_b - 1) / sub_b;
 	sub_b = (n_batches + n_sub - 1) / n_sub;
 	use_alt = self->overlap && self->alt && device_call && (n_sub > 1 || self->relaxed);
+	if (self->log2n == 16 && self->k1h_fused)
+		use_alt = 0;		/* one fused FFT kernel at a time: its clusters own the counters and the intermediate */
 
 	/* A call that stores every row of the ring does so in the other ring: its K1s then owe nothing to the
 	 * row stores of the calls before it.  Otherwise the untouched rows must survive: same ring. */
@@ -1110,6 +1148,11 @@ extern "C" int fosphor_amd_finish(struct fosphor *self)
 	}
 	if (sync_all(self))
 		return -EIO;
+	if (self->h_k1h_err && self->h_k1h_err[0]) {
+		fprintf(stderr, "[fosphor_amd] fused 65536-point FFT: work-group %u is not on the XCD its cluster expects; "
+		        "results are invalid (set FOSPHOR_AMD_K1H_FUSED=0)\n", self->h_k1h_err[0] - 1);
+		return -EIO;
+	}
 	self->state = ST_READY;
 	return 1;
 }
@@ -1129,6 +1172,13 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 {
 	if (!self || !out)
 		return -EINVAL;
+	if (self->last_hc16 && self->export_src) {
+		/* behind the K2 that wrote the slabs; the view is complete when this call returns */
+		if (launch_export_hc16(self->export_src, self->d_hc_export, self->n_bins, self->n, self->stream2) != hipSuccess ||
+		    hipStreamSynchronize(self->stream2) != hipSuccess)
+			return -EIO;
+		self->export_src = NULL;
+	}
 	out->d_waterfall = self->d_wf_pp[self->wf_cur];
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
@@ -1240,7 +1290,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 		if (sub_c < 1) sub_c = 1;
 		if (chunked && cpb > sub_c) {
 			const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
-			const int use_alt = self->overlap && self->alt;
+			const int use_alt = self->overlap && self->alt && !(self->log2n == 16 && self->k1h_fused);
 			int used_alt = 0;
 			if (drain_h_sets(self, st2))
 				return -EIO;

@@ -43,6 +43,10 @@ struct K1Params {
 	long long    *dbg;		/* K1_TIMING builds: [waves][8] cycle accumulators, or nullptr */
 	float2       *scratch;		/* variant 4: [total][N] intermediate spectrum between the two stages */
 	int   iq_half;			/* variant 4: the IQ stream is fp16 (re, im) pairs, 4 B per sample */
+	uint32_t *sync;			/* variant 4, fused form: cluster counters [64][64]; nullptr = two kernels */
+	uint32_t *sync_err;		/* ... its error word (host-mapped) */
+	int   dbg_k1h;			/* measurement only (FOSPHOR_AMD_DBG_K1H): 1 no cluster waits, 2 no IQ loads, 4 no row / bin stores,
+					 * 8 no intermediate stores / loads -- results are wrong with any of them */
 	int   total;			/* spectra in this launch */
 	int   tile;			/* spectra per wave: 4, 8 or 16 */
 	int   wf_pos0, wf_mask;		/* ring position of spectrum 0, wf_rows-1 */
@@ -98,7 +102,8 @@ struct K2bParams {
 struct K3Params {
 	const uint32_t *hc;		/* [n_batches][n_bins][N] */
 	const uint16_t *hc16;		/* or slab-major 16-bit counts, see K2Params */
-	uint32_t *hc_export;		/* hc16 path: [n_bins][N] counts of the last batch, for the API view */
+	uint32_t *hc_export;		/* hc16 path: [n_bins][N] counts of the last batch, for the API view; nullptr: not written
+					 * (large states, the view is made on demand from the last batch's slabs) */
 	const float    *live_sum;	/* [n_batches][N] */
 	const float    *vmax;		/* [n_batches][N] */
 	float  *hist;			/* [n_bins][N] */
@@ -136,6 +141,7 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
+hipError_t launch_export_hc16(const uint16_t *hc16, uint32_t *out, int n_bins, int n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
 

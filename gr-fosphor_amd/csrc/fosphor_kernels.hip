@@ -2008,6 +2008,359 @@ void k1h_stage_b(const K1Params p)
 	}
 }
 
+/* ---- both stages in one kernel, the intermediate spectrum resident in the XCD's L2 ---------------------------
+ * The two-kernel form above moves 8 B per sample out of the L2 and 8 B back in (next to 4 B of fp16 IQ): the
+ * L2 <-> fabric links, not the Infinity Cache behind them, bound it.  Here a CLUSTER of 8 work-groups on ONE XCD
+ * (work-groups b with equal b % 8 share an XCD: the dispatcher deals them round-robin; checked against XCC_ID,
+ * a mismatch is reported to the host) takes a spectrum through both stages:
+ *   stage A  member m transforms residues [16 m, 16 m + 16) (k1h_stage_a's work item) and stores its 16 blocks
+ *            into the cluster's 512 KiB intermediate;
+ *   cluster barrier (arrive / wait counters in memory, relaxed agent-scope atomics: they and the plain stores
+ *            meet in the XCD's L2, which is the coherence point of its CUs -- no L2 write-back, no invalidate);
+ *   stage B  member m transforms offsets k in [64 m, 64 m + 64) (two of k1h_stage_b's work items side by side,
+ *            one `a` per wave) reading the intermediate with L1-bypassing loads: L2 hits, the 32 clusters'
+ *            16 MiB never has to leave the chip;
+ *   the next spectrum's stage-A stores wait for every member's stage-B reads (second counter; the wait sits
+ *            after stage A's arithmetic, so it is normally already satisfied).
+ * The next spectrum's IQ is requested before the wait for stage A; window taps and the stage-B twiddles of a
+ * thread never change (its residues / offsets are fixed) and stay in registers.  A cluster owns whole tiles of
+ * spectra (live / max partials in registers across the tile).  Arithmetic: the same helpers in the same order
+ * as the two-kernel form, hence the same bits. */
+static __device__ __forceinline__ v2f load_l2(const v2f *ptr)
+{
+	/* agent-scope relaxed load: global_load_dwordx2 ... sc1, misses the CU's L1 by construction */
+	const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr),
+	                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	v2f r;
+	r.x = __uint_as_float((uint32_t)u);
+	r.y = __uint_as_float((uint32_t)(u >> 32));
+	return r;
+}
+
+template <bool HALF, bool WRITE_FFT>
+__global__ __launch_bounds__(1024, 4)
+void k1h_fused(const K1Params p)
+{
+	constexpr int N = 65536, QA = 16, M = 512, ROW = M + 1, KB = 64;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	v2f *l4 = reinterpret_cast<v2f *>(smem_raw);			/* stage B, after pass 4: [(i3, jj4)][k]; after pass 5 */
+	v2f *l5 = l4;
+	v2f *rows = reinterpret_cast<v2f *>(smem_raw);			/* stage A: 16 rows of 513 (aliases l4) */
+	v2f *tws = rows + QA * ROW;					/* stage A twiddles, passes p = 8, 64 */
+	v2f *t4 = tws + (8 + 64) * 7;					/* stage B twiddles of this member's 64 offsets: [j][k] */
+	v2f *t5 = t4 + 7 * KB;						/* [jj4][j][k] */
+	v2f *t6 = t5 + 8 * 7 * KB;					/* [m][k] */
+
+	const int tid = threadIdx.x;
+	/* Cluster formation.  A work-group takes a ticket from the counter of the XCD it actually runs on (XCC_ID):
+	 * tickets 8c .. 8c + 7 of an XCD are cluster c of that XCD, whatever the dispatcher did.  A cluster works once
+	 * its 8 members are resident; complete clusters claim tiles until none is left, and a cluster still forming
+	 * when the tiles run out (another kernel holds the CUs its members need) is abandoned as a whole: progress
+	 * never depends on a work-group that is not resident. */
+	__shared__ int sh_ticket, sh_tile;
+	uint32_t xcc;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+	xcc &= 7;
+	uint32_t *next_tile = p.sync + 63 * 64 + 56;		/* (on the last cluster's line; tickets sit at word 48) */
+	const int ntiles = p.total / p.tile;
+	if (tid == 0) {
+		uint32_t *tick = p.sync + xcc * 8 * 64 + 48;		/* on the line of the XCD's first cluster */
+		const uint32_t tk = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		int ok = 0;
+		if (tk < 64) {
+			/* the cluster's state: 0 forming, 1 complete (set by the holder of its 8th ticket: all 8 are resident),
+			 * 2 abandoned (set by a member that saw the tiles run out first) -- one compare-and-swap decides */
+			uint32_t *state = p.sync + ((int)xcc * 8 + (int)(tk >> 3)) * 64 + 24;
+			uint32_t st = 0;
+			if ((tk & 7) == 7) {
+				__hip_atomic_compare_exchange_strong(state, &st, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			} else {
+				while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+					if ((int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntiles) {
+						uint32_t expect = 0;
+						__hip_atomic_compare_exchange_strong(state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+					__builtin_amdgcn_s_sleep(8);
+				}
+			}
+			ok = (st == 1);
+		}
+		sh_ticket = ok ? (int)tk : -1;
+	}
+	__syncthreads();
+	if (sh_ticket < 0)
+		return;
+	const int member = sh_ticket & 7;
+	const int gc = (int)xcc * 8 + (sh_ticket >> 3);			/* cluster: up to 8 per XCD */
+	uint32_t *c_a = p.sync + gc * 64;				/* stage A done */
+	uint32_t *c_t = p.sync + gc * 64 + 16;				/* (round << 20) | tile, published by member 0 */
+	uint32_t *c_b = p.sync + gc * 64 + 32;				/* stage B has read the intermediate */
+	v2f *w = reinterpret_cast<v2f *>(p.scratch) + (size_t)gc * N;
+
+	/* stage A geometry: residue q0 + (tid & 15), sub-FFT work-item tid >> 4; stage B: offset 64 member + (tid & 63),
+	 * a = tid >> 6 (one per wave).  The per-lane parts are re-derived from an opaque copy of tid inside the loops:
+	 * hoisted, the 64-bit addresses they feed cost more registers than the kernel has. */
+	const int q0 = member * QA;
+	const int a = __builtin_amdgcn_readfirstlane(tid >> 6);	/* 0..15 */
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	/* per-thread constants */
+	float wina[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		wina[j] = p.win[q0 + (tid & (QA - 1)) + 128 * ((tid >> 4) + 64 * j)];
+	/* twiddle tables of the block, loaded once (a thread's stage-B twiddles depend on (k, a) only) */
+	for (int e = tid; e < (8 + 64) * 7; e += 1024)
+		tws[e] = twg[e];
+	for (int e = tid; e < 7 * KB; e += 1024)
+		t4[e] = twg[p.tw_off[2] + (member * KB + (e & (KB - 1))) * 7 + (e >> 6)];
+	for (int e = tid; e < 8 * 7 * KB; e += 1024) {
+		const int kk = e & (KB - 1), j = (e >> 6) % 7, jj4 = (e >> 6) / 7;
+		t5[e] = twg[p.tw_off[3] + (member * KB + kk + 512 * jj4) * 7 + j];
+	}
+	for (int e = tid; e < 64 * KB; e += 1024)
+		t6[e] = twg[p.tw_off[4] + member * KB + (e & (KB - 1)) + 512 * (e >> 6)];
+	__syncthreads();
+
+	uint32_t done = 0;						/* spectra this cluster has finished */
+	uint32_t round = 0;						/* tiles this cluster has taken */
+
+	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+	h2  xh[8];
+	v2f xf[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) { xh[j] = h2{ (_Float16)0.25f, (_Float16)0.5f }; xf[j] = v2f{ 0.25f, 0.5f }; }	/* (only seen with dbg_k1h & 2) */
+	auto fetch_iq = [&](int t) {
+		if (p.dbg_k1h & 2)
+			return;
+		int tl = tid;
+		asm volatile("" : "+v"(tl));
+		const int nb0 = q0 + (tl & (QA - 1)) + 128 * (tl >> 4);
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			const int n = nb0 + 128 * 64 * j;
+			if (HALF)
+				xh[j] = __builtin_nontemporal_load(reinterpret_cast<const h2 *>(p.iq) + (size_t)t * p.hop + n);
+			else
+				xf[j] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p.iq + (size_t)t * p.hop + n));
+		}
+	};
+	for (;;) {
+	/* member 0 claims the cluster's next tile */
+	if (tid == 0) {
+		uint32_t v;
+		if (member == 0) {
+			v = __hip_atomic_fetch_add(next_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (v > 0xfffffu) v = 0xfffffu;
+			__hip_atomic_store(c_t, ((round + 1) << 20) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			while (((v = __hip_atomic_load(c_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != round + 1)
+				__builtin_amdgcn_s_sleep(2);
+			v &= 0xfffffu;
+		}
+		sh_tile = (int)v;
+	}
+	__syncthreads();
+	const int tile = sh_tile;
+	round++;
+	if (tile >= ntiles)
+		break;
+	const int t0 = tile * p.tile;
+	fetch_iq(t0);
+	float live[8], vmax[8];
+	uint32_t pack[8];
+#pragma unroll
+	for (int c = 0; c < 8; c++) { live[c] = 0.0f; vmax[c] = vmax_init; pack[c] = 0; }
+
+#pragma unroll 1
+	for (int u = 0; u < p.tile; u++) {
+		const int t = t0 + u;
+		v2f r[8];
+		int tl = tid;
+		asm volatile("" : "+v"(tl));
+		const int ql = tl & (QA - 1), ia = tl >> 4;
+		v2f *buf = rows + ql * ROW;
+		const int kl = tl & (KB - 1);
+		const int k = member * KB + kl;
+
+		/* ================= stage A: residues q0 .. q0 + 15 ================= */
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			v2f xv;
+			if (HALF)
+				xv = v2f{ (float)xh[j].x, (float)xh[j].y };	/* v_cvt_f32_f16: exact */
+			else
+				xv = xf[j];
+			r[j] = v2f{ xv.x * wina[j], xv.y * wina[j] };		/* fft.cl:415-417 */
+		}
+		{
+			int pp = 1;
+#pragma unroll
+			for (int q8 = 0; q8 < 3; q8++) {
+				const int kk = ia & (pp - 1);
+				if (q8 > 0) {
+					const v2f *tw = tws + p.tw_off[q8 - 1] + kk * 7;
+#pragma unroll
+					for (int j = 1; j < 8; j++)
+						r[j] = c_mul(r[j], tw[j - 1]);
+				}
+				dft8(r, s12);
+				const int j0 = ((ia - kk) << 3) + kk;
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++)
+					buf[j0 + jj * pp] = r[R8_PERM(jj)];
+				__syncthreads();
+				if (q8 < 2) {
+#pragma unroll
+					for (int j = 0; j < 8; j++)
+						r[j] = buf[ia + 64 * j];
+					__syncthreads();
+				}
+				pp <<= 3;
+			}
+		}
+		/* every member has read the previous spectrum out of the intermediate? */
+		if (tid == 0 && !(p.dbg_k1h & 1)) {
+			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0)
+				__builtin_amdgcn_s_sleep(1);
+		}
+		__syncthreads();
+		if (!(p.dbg_k1h & 8)) {
+			v2f *dst = w + (size_t)M * q0;
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				const int idx = tl + 1024 * c;
+				dst[idx] = rows[(idx >> 9) * ROW + (idx & (M - 1))];
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* this wave's blocks are in the L2 */
+		__syncthreads();
+		if (tid == 0)
+			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+		/* the tile's next spectrum, requested now */
+		if (u + 1 < p.tile)
+			fetch_iq(t + 1);
+
+		if (tid == 0 && !(p.dbg_k1h & 1)) {
+			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0)
+				__builtin_amdgcn_s_sleep(1);
+		}
+		__syncthreads();
+		asm volatile("" ::: "memory");
+
+		/* ================= stage B: offsets k = 64 member .. + 63 ================= */
+		if (!(p.dbg_k1h & 8)) {
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = load_l2(w + 512 * (a + 16 * j) + k);
+		}
+#pragma unroll
+		for (int j = 1; j < 8; j++)
+			r[j] = c_mul(r[j], t4[(j - 1) * KB + kl]);
+		dft8(r, s12);
+#pragma unroll
+		for (int jj = 0; jj < 8; jj++)
+			l4[(a * 8 + jj) * KB + kl] = r[R8_PERM(jj)];
+		__syncthreads();
+		if (tid == 0)							/* everybody's loads of the intermediate have landed */
+			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		done++;
+		{
+			const int i4 = a >> 3, jj4 = a & 7;
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				r[j] = l4[((i4 + 2 * j) * 8 + jj4) * KB + kl];
+#pragma unroll
+			for (int j = 1; j < 8; j++)
+				r[j] = c_mul(r[j], t5[(jj4 * 7 + j - 1) * KB + kl]);
+			dft8(r, s12);
+			__syncthreads();				/* l5 is l4: every read of pass 4's results is done */
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				l5[(i4 * 64 + jj * 8 + jj4) * KB + kl] = r[R8_PERM(jj)];
+		}
+		__syncthreads();
+		v2f x[8];
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const int mm = 4 * a + c;
+			v2f va = l5[mm * KB + kl];
+			v2f vb = l5[(64 + mm) * KB + kl];
+			vb = c_mul(vb, t6[mm * KB + kl]);
+			DFT2(va, vb);
+			x[c] = va;
+			x[c + 4] = vb;
+		}
+		__syncthreads();					/* l4 / l5 become stage A's rows again */
+
+		if (WRITE_FFT) {
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const int jcol = k + 512 * (4 * a + c);
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol] = x[c];
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol + N / 2] = x[c + 4];
+			}
+		}
+
+		/* epilogue (display.cl:136,161-168), 16-bit bin indices */
+		float l2[8];
+		uint32_t bn[8];
+		uint32_t amb = 0;
+#pragma unroll
+		for (int c = 0; c < 8; c++) {
+			uint32_t ab;
+			const float rr = bin_fast(x[c].x, x[c].y, bk, &l2[c], &ab);
+			amb = amb > ab ? amb : ab;
+			bn[c] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
+		}
+		if (amb > __float_as_uint(bk.amb)) {
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				const float v = __builtin_fmaf(bk.A, l2[c], bk.C);
+				const float rr = __builtin_rintf(v);
+				const float am = __builtin_fmaf(__builtin_fabsf(l2[c]), bk.kappa, __builtin_fabsf(v - rr));
+				if (!(am <= bk.amb)) {
+					float nl2;
+					bn[c] = bin_exact(x[c].x, x[c].y, l2[c], (int)bn[c], bk.thr, bk.nb, &nl2);
+					l2[c] = nl2;
+				}
+			}
+		}
+		const bool store_row = (t >= p.wf_first) && !(p.dbg_k1h & 4);
+		float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * N;
+#pragma unroll
+		for (int c = 0; c < 8; c++) {
+			const int col = k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2);
+			pack[c] |= bn[c] << (16 * (u & 1));
+			live[c] = __builtin_fmaf(live[c], p.w, l2[c]);
+			vmax[c] = max_f32(vmax[c], l2[c]);
+			if (store_row)
+				wf_row[col] = l2[c] * F_HALF_LOG10_2;
+		}
+		if ((u & 1) && !(p.dbg_k1h & 4)) {
+			uint32_t *dst = p.bins + (size_t)(t >> 1) * N;
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				dst[k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2)] = pack[c];
+				pack[c] = 0;
+			}
+		}
+	}
+	float2 *pp2 = p.partial + (size_t)tile * N;
+	const int k = member * KB + (tid & (KB - 1));
+#pragma unroll
+	for (int c = 0; c < 8; c++)
+		pp2[k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2)] = make_float2(live[c] * F_HALF_LOG10_2,
+			(vmax[c] == vmax_init) ? -1000.0f : vmax[c] * F_HALF_LOG10_2);
+	}
+}
+
 static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 {
 	constexpr size_t lds_a = ((size_t)16 * 513 + (8 + 64) * 7) * sizeof(float2);
@@ -2017,6 +2370,28 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
 		attr_set = true;
+	}
+	if (p0.sync) {
+		/* fused form: 32 clusters of 8 work-groups, one work-group per CU */
+		constexpr size_t lds_f = ((size_t)16 * 513 + (8 + 64) * 7 + 7 * 64 + 8 * 7 * 64 + 64 * 64) * sizeof(float2);
+		static bool attr_f = false;
+		if (!attr_f) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+			attr_f = true;
+		}
+		if (hipMemsetAsync(p0.sync, 0, 64 * 64 * sizeof(uint32_t), s) != hipSuccess)	/* the counters; not the error word behind them */
+			return hipErrorLaunchFailure;
+		if (p0.iq_half) {
+			if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<true, true>), dim3(256), dim3(1024), lds_f, s, p0);
+			else            hipLaunchKernelGGL((k1h_fused<true, false>), dim3(256), dim3(1024), lds_f, s, p0);
+		} else {
+			if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<false, true>), dim3(256), dim3(1024), lds_f, s, p0);
+			else            hipLaunchKernelGGL((k1h_fused<false, false>), dim3(256), dim3(1024), lds_f, s, p0);
+		}
+		return hipGetLastError();
 	}
 	/* Stage A and stage B alternate over groups of spectra whose intermediate (8 B per sample, fp32) fits the
 	 * Infinity Cache: the round trip between the stages then mostly stays on the die instead of costing 16 B of
@@ -2470,7 +2845,8 @@ void k3_merge(const K3Params p)
 			const int bin = rem >> 6;
 			const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
 			const int hidx = bin * p.n + slab * 64 + col;
-			float hv = p.hist[hidx];
+			const float hv0 = p.hist[hidx];
+			float hv = hv0;
 			int f = 0;
 			uint32_t last = 0;
 			for (; f + 8 <= p.n_batches; f += 8) {
@@ -2499,8 +2875,11 @@ void k3_merge(const K3Params p)
 				}
 				last = hc;
 			}
-			p.hist[hidx] = hv;
-			p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers) */
+			if (__float_as_uint(hv) != __float_as_uint(hv0))
+				p.hist[hidx] = hv;	/* cold cells (display.cl:237-238) keep their line clean */
+			if (p.hc_export)
+				p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers);
+								 * large states: made on demand by k_export_hc16 instead */
 		}
 	}
 	if (MODE == 0 || MODE == 3) {
@@ -2843,6 +3222,28 @@ __global__ void k_fill(float *dst, float value, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
 		dst[i] = value;
+}
+
+/* uint32 [bin][x] view of one batch of 16-bit slab-major counts (the layout K3 mode 0 / 3 reads) */
+__global__ __launch_bounds__(256)
+void k_export_hc16(const uint16_t *__restrict__ hc16, uint32_t *__restrict__ out, int n_bins, int n)
+{
+	const size_t cells = (size_t)n_bins * n;
+	for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < cells; gid += (size_t)gridDim.x * 256) {
+		const int slab = (int)(gid / ((size_t)n_bins * 64));
+		const int rem = (int)(gid - (size_t)slab * n_bins * 64);
+		const int bin = rem >> 6;
+		const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
+		out[(size_t)bin * n + slab * 64 + col] = hc16[gid];
+	}
+}
+
+hipError_t launch_export_hc16(const uint16_t *hc16, uint32_t *out, int n_bins, int n, hipStream_t s)
+{
+	size_t blocks = ((size_t)n_bins * n + 255) / 256;
+	if (blocks > 8192) blocks = 8192;
+	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, out, n_bins, n);
+	return hipGetLastError();
 }
 
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s)

@@ -1029,6 +1029,65 @@ def test_c5_sharded_two_ranks(amd, torch_cuda, oracle_built):
         fr.close()
 
 
+def _c5_outputs(f):
+    return [canon_bits(f.waterfall), canon_bits(f.histogram), canon_bits(f.spectrum), f.hitcount.copy()]
+
+
+@pytest.mark.parametrize("tile", [None, "4"])
+def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
+    """N = 65536: the fused two-stage kernel (clusters of 8 work-groups per XCD, intermediate spectrum resident in
+    the XCD's L2) against the two-kernel form (FOSPHOR_AMD_K1H_FUSED=0): every output bit-identical, over calls
+    whose tile counts do not divide evenly among the clusters, multi-batch calls and a ring wrap.  (The two forms
+    pick different tile lengths for the live partials; with the same length forced the live spectrum is bit-identical
+    too, otherwise it is compared within the float tolerance.)"""
+    torch = torch_cuda
+    n, nb, rows = 65536, 512, 64
+    if tile:
+        monkeypatch.setenv("FOSPHOR_AMD_TILE", tile)
+    else:
+        monkeypatch.delenv("FOSPHOR_AMD_TILE", raising=False)
+    monkeypatch.delenv("FOSPHOR_AMD_K1H_FUSED", raising=False)
+    fa = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=160, max_batches=4, iq_fp16=True)
+    monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", "0")
+    fb = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=160, max_batches=4, iq_fp16=True)
+    monkeypatch.delenv("FOSPHOR_AMD_K1H_FUSED", raising=False)
+    for call, (nbat, batch) in enumerate([(1, 16), (1, 144), (3, 48), (2, 80), (1, 160)]):
+        x = add_tone(gaussian_iq(nbat * batch * n, 301 + call), 0.04, 0.11 + 0.05 * call).astype(np.float16)
+        d = torch.from_numpy(x).cuda()
+        assert fa.process_device(d, nbat, batch) == 0 and fb.process_device(d, nbat, batch) == 0
+        assert fa.finish() >= 0 and fb.finish() >= 0
+        assert int(fa.hitcount.sum()) == batch * n
+        for got, want, what in zip(_c5_outputs(fa), _c5_outputs(fb), ("waterfall", "histogram", "spectrum", "hit counts")):
+            if what == "spectrum" and not tile:
+                assert_close(fa.spectrum[:, :, 1], fb.spectrum[:, :, 1], "call %d: spectrum" % call)
+            else:
+                assert np.array_equal(got, want), "call %d: %s" % (call, what)
+    fa.close(); fb.close()
+
+
+def test_c5_fused_instances_side_by_side(amd, torch_cuda):
+    """Three N = 65536 instances with work queued at the same time on their own streams: the clusters of the fused
+    kernels form from whatever work-groups are resident (no kernel waits for a work-group that is not), all three
+    finish and agree."""
+    torch = torch_cuda
+    n, nb, rows = 65536, 512, 64
+    fs = [amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=128, iq_fp16=True) for _ in range(3)]
+    x = add_tone(gaussian_iq(128 * n, 311), 0.05, 0.37).astype(np.float16)
+    d = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for f in fs:
+            assert f.process_device(d, 1, 128) == 0
+    for f in fs:
+        assert f.finish() >= 0
+    ref = _c5_outputs(fs[0])
+    for f in fs[1:]:
+        for got, want in zip(_c5_outputs(f), ref):
+            assert np.array_equal(got, want)
+    for f in fs:
+        f.close()
+
+
 @pytest.mark.parametrize("n_bins,wf_rows,consts", [
     (16, 1024, None), (64, 256, None), (192, 1024, (4.0, 256.0, 0.01)), (256, 2048, (32.0, 4096.0, 0.0005)),
 ])
