@@ -43,7 +43,6 @@ static const int kSets = 5;		/* intermediate (bin index / partial) sets in rotat
 static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams */
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
-static const size_t kLazyExportBytes = (size_t)32 << 20;	/* hit-count views this large are made on demand (fosphor_amd_get_buffers) */
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
 
 struct fosphor
@@ -111,7 +110,12 @@ struct fosphor
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
-	const uint16_t *export_src;		/* ... or made from these slabs when fosphor_amd_get_buffers asks */
+	const uint16_t *export_src;		/* ... made from the last batch's slabs when fosphor_amd_get_buffers asks */
+	const uint32_t *export_mask;
+	uint32_t *d_rowmask;			/* K2 -> K3: one bit per (batch, slab, bin row) "this row has counts and is stored"; 2 sets */
+	int       mask_words;			/* ceil(n_bins / 32) */
+	uint8_t  *d_hot;			/* [N/64][n_bins]: some cell of the row is above the fast-exit level (K3 maintains it) */
+	int       hot_valid;			/* 0 after anything but the 16-bit K3 wrote the histogram */
 	uint16_t *d_slab16;			/* per-chunk packed 16-bit count slabs of batches longer than 1024 spectra / of a shard */
 	int       slab_chunks;			/* capacity of d_slab16 in 1024-spectrum chunks */
 	int       last_hc16;
@@ -264,6 +268,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	}
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
+	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -436,6 +441,11 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
+	self->mask_words = (self->n_bins + 31) / 32;
+	HIP_TRY(hipMalloc((void **)&self->d_rowmask, sizeof(uint32_t) * 2 * (size_t)self->max_batches * (self->n / 64) * self->mask_words), "alloc row masks");
+	HIP_TRY(hipMalloc((void **)&self->d_hot, (size_t)(self->n / 64) * self->n_bins), "alloc row flags");
+	HIP_TRY(hipMemset(self->d_hot, 1, (size_t)(self->n / 64) * self->n_bins), "set row flags");
+	self->hot_valid = 0;
 	if (self->max_spectra > 1024) {
 		/* one slab per 1024-spectrum chunk of the largest launch: a whole shard (accumulate) or a sub-launch */
 		self->slab_chunks = self->max_spectra / 1024;
@@ -703,6 +713,16 @@ static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
 	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !getenv("FOSPHOR_AMD_NO_BIGCHUNK");
 }
 
+/* Sparse K2 -> K3 hand-off (row masks + hot flags): pays where the state is large (N = 8192: 16 MiB, N = 65536:
+ * 128 MiB -- K3 then reads the 1 row in 5 that is alive instead of everything); at N = 1024 K3 is bound by its
+ * 64-batch dependent chain, not by the rows it touches, and K2's mask costs more than K3 saves (measured -1 %).
+ * FOSPHOR_AMD_ROWMASK=0 / 1 forces it off / on. */
+static int use_rowmask(const struct fosphor *self)
+{
+	const char *e = getenv("FOSPHOR_AMD_ROWMASK");
+	return e ? (*e != '0') : self->log2n != 10;
+}
+
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
@@ -727,8 +747,13 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	k2.hc = self->d_hc + (size_t)slot0 * cells;
 	k2.hc16 = (use16 && (batch <= 1024 || one_chunk) && self->rise_ok(batch))
 	          ? (uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
+	if (k2.hc16 && use_rowmask(self)) {
+		k2.rowmask = self->d_rowmask + (size_t)hset * self->max_batches * (self->n / 64) * self->mask_words;
+		k2.mask_words = self->mask_words;
+		k2.mask_stride = self->max_batches;
+	}
 	if (sum16)
-		k2.hc16 = self->d_slab16;
+		k2.hc16 = self->d_slab16, k2.rowmask = NULL;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
@@ -806,12 +831,26 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.hc16 = (use16 && (batch <= 1024 || one_chunk) && have_table)
 	          ? (const uint16_t *)self->d_hc + (size_t)hset * self->max_batches * cells : NULL;
 	k3.hc_export = self->d_hc_export;
-	if (k3.hc16 && cells * sizeof(uint32_t) >= kLazyExportBytes) {
-		/* a view as large as the state itself (N = 65536: 128 MiB per batch) is made when somebody asks for it */
+	if (k3.hc16) {
+		/* the uint32 view of the last batch is made when somebody asks for it (fosphor_amd_get_buffers) */
+		const size_t per_batch = (size_t)(self->n / 64) * self->mask_words;
 		k3.hc_export = NULL;
 		self->export_src = k3.hc16 + (size_t)(n_batches - 1) * cells;
+		self->export_mask = NULL;
+		if (use_rowmask(self)) {
+			k3.rowmask = self->d_rowmask + (size_t)hset * self->max_batches * per_batch;
+			k3.mask_words = self->mask_words;
+			k3.mask_stride = self->max_batches;
+			self->export_mask = k3.rowmask + (n_batches - 1);
+			k3.hot = self->d_hot;
+			k3.hot_all = !self->hot_valid;
+			self->hot_valid = 1;
+		} else {
+			self->hot_valid = 0;
+		}
 	} else {
 		self->export_src = NULL;
+		self->hot_valid = 0;
 	}
 	k3.live_sum = self->d_live_sum + (size_t)lslot * self->n;
 	k3.vmax = self->d_vmax + (size_t)lslot * self->n;
@@ -844,6 +883,7 @@ static int run_k23(struct fosphor *self, int n_batches, int batch, int tile, hip
 	k.hist = self->d_hist; k.spectrum = self->d_spectrum;
 	k.hc_export = self->d_hc_export;
 	self->export_src = NULL;
+	self->hot_valid = 0;
 	k.rise = self->d_rise;
 	k.n = self->n; k.n_bins = self->n_bins; k.n_batches = n_batches; k.batch = batch; k.tile = tile;
 	k.log2_w = (float)log2((double)(1.0f - self->alpha));
@@ -1174,7 +1214,7 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 		return -EINVAL;
 	if (self->last_hc16 && self->export_src) {
 		/* behind the K2 that wrote the slabs; the view is complete when this call returns */
-		if (launch_export_hc16(self->export_src, self->d_hc_export, self->n_bins, self->n, self->stream2) != hipSuccess ||
+		if (launch_export_hc16(self->export_src, self->export_mask, self->mask_words, self->max_batches, self->d_hc_export, self->n_bins, self->n, self->stream2) != hipSuccess ||
 		    hipStreamSynchronize(self->stream2) != hipSuccess)
 			return -EIO;
 		self->export_src = NULL;

@@ -86,6 +86,11 @@ struct K2Params {
 	 * of a batch of weight_batch spectra; single GPU: t_offset 0, weight_batch = batch */
 	int   t_offset, weight_batch;
 	int   dbg_same;			/* measurement only: every chunk reads and writes chunk 0's memory (no HBM traffic) */
+	uint32_t *rowmask;		/* hc16 hand-off to K3: [N/64][mask_words][mask_stride >= chunks] one bit per bin row of the slab (the
+					 * batches of a row side by side: K3 fetches a row's 64 batches in one request); rows whose 64
+					 * counts are all zero are NOT stored and their bit is clear (nullptr: every row is stored) */
+	int   mask_words;		/* ceil(n_bins / 32) */
+	int   mask_stride;
 };
 
 struct K2bParams {
@@ -115,6 +120,12 @@ struct K3Params {
 	int   dbg_same;			/* measurement only: every batch reads batch 0's counts */
 	int   cell_begin, cell_end;	/* cells [begin, end) of the (bin, x) array are updated (0, 0 = all): the
 					 * frequency-sliced merge of the multi-GPU split; the columns always are */
+	const uint32_t *rowmask;	/* hc16 path: K2's row bits (see K2Params) */
+	int   mask_words, mask_stride;
+	uint8_t *hot;			/* hc16 path: [N/64][n_bins] "some cell of this 64-cell row is above the fast-exit level
+					 * (display.cl:237)", maintained here; a row that is not hot and has no count in any batch of
+					 * the launch is skipped without reading its cells */
+	int   hot_all;			/* the flags are stale (another kernel wrote the histogram): visit every row, rewrite them */
 };
 
 /* K23: hit counts AND state update in one kernel (N = 1024 path, 8-bit bin indices, batch <= 1024).
@@ -141,7 +152,7 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
-hipError_t launch_export_hc16(const uint16_t *hc16, uint32_t *out, int n_bins, int n, hipStream_t s);
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
 

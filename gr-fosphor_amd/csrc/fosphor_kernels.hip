@@ -2585,8 +2585,11 @@ void k2_count(const K2Params p)
 	const int hcol = lane & 31;
 	const uint32_t inc = (lane & 32) ? 0x10000u : 1u;
 
+	__shared__ uint32_t rowbits[16];		/* n_bins <= 512 */
 	for (int i = tid; i < nb * 32; i += 64 * NW)
 		h[i] = 0;
+	if (tid < 16)
+		rowbits[tid] = 0;
 	__syncthreads();
 
 	/* bins: one dword = 4 consecutive spectra of one column (8-bit indices), or 2 (16-bit
@@ -2680,6 +2683,24 @@ void k2_count(const K2Params p)
 		/* the LDS image as it is: [bin][32] packed pairs, one contiguous block per work-group
 		 * (32 KiB at 256 bins); K3 unpacks */
 		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)c * (p.n / 64) + blockIdx.x) * nb * 32;
+		if (p.rowmask) {
+			/* sparse hand-off: only the bin rows with a count are stored (a wave covers two rows of 32 dwords per
+			 * step), one bit per row tells K3 which; with noise-like input 4 rows in 5 are empty */
+			for (int i = tid; i < nb * 32; i += 64 * NW) {
+				const uint32_t v = h[i];
+				const unsigned long long bal = __ballot(v != 0);
+				const uint32_t nz = (lane & 32) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+				if (nz) {
+					d[i] = v;
+					if ((lane & 31) == 0)
+						atomicOr(&rowbits[i >> 10], 1u << ((i >> 5) & 31));
+				}
+			}
+			__syncthreads();
+			if (tid < p.mask_words)
+				p.rowmask[((size_t)blockIdx.x * p.mask_words + tid) * p.mask_stride + c] = rowbits[tid];
+			return;
+		}
 #pragma unroll 2
 		for (int i = tid; i < nb * 32; i += 64 * NW)
 			d[i] = h[i];
@@ -2816,7 +2837,7 @@ hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
  * (batches of up to 8192 spectra counted as one chunk); 1: 32-bit counts + (d, e) table in memory;
  * 2: 32-bit counts, (d, e) evaluated per cell (batches beyond the table).  Separate instantiations keep
  * the common one (0) at a register budget that lets it share a SIMD with K1. */
-template <int MODE>
+template <int MODE, bool SPARSE = false>
 __global__ __launch_bounds__(256)
 void k3_merge(const K3Params p)
 {
@@ -2845,41 +2866,64 @@ void k3_merge(const K3Params p)
 			const int bin = rem >> 6;
 			const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
 			const int hidx = bin * p.n + slab * 64 + col;
+			const int row = slab * nb + bin;			/* one wave = the 64 cells of one (slab, bin) row */
+			const int lane = threadIdx.x & 63;
+			/* K2's row bits of every batch of the launch for this row: lane l asks for batch f0 + l */
+			const bool was_hot = !SPARSE || p.hot_all || p.hot[row] != 0;
+			bool any = was_hot;
+			if (SPARSE && !any) {
+				for (int f0 = 0; f0 < p.n_batches && !any; f0 += 64) {
+					const int fl = f0 + lane;
+					const uint32_t wd = (fl < p.n_batches)
+					        ? p.rowmask[((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
+					any = __ballot((wd >> (bin & 31)) & 1u) != 0;
+				}
+			}
+			if (!SPARSE || any) {
 			const float hv0 = p.hist[hidx];
 			float hv = hv0;
-			int f = 0;
-			uint32_t last = 0;
-			for (; f + 8 <= p.n_batches; f += 8) {
-				uint32_t hc[8];
+			for (int f0 = 0; f0 < p.n_batches; f0 += (SPARSE ? 64 : p.n_batches)) {
+				unsigned long long m = ~0ull;
+				if (SPARSE) {
+					const int fl = f0 + lane;
+					const uint32_t wd = (fl < p.n_batches)
+					        ? p.rowmask[((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
+					m = __ballot((wd >> (bin & 31)) & 1u);
+				}
+				const int fe = (!SPARSE || p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
+				int f = f0;
+				for (; f + 8 <= fe; f += 8) {
+					uint32_t hc[8];
 #pragma unroll
-				for (int u = 0; u < 8; u++)
-					hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
+					for (int u = 0; u < 8; u++)
+						hc[u] = (!SPARSE || ((m >> (f + u - f0)) & 1ull))
+						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]) : 0u;
 #pragma unroll
-				for (int u = 0; u < 8; u++) {
-					if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
-						const float2 de = (MODE == 0) ? rise_lds[hc[u]] : p.rise[hc[u]];
-						hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
-						hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
+					for (int u = 0; u < 8; u++) {
+						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
+							const float2 de = (MODE == 0) ? rise_lds[hc[u]] : p.rise[hc[u]];
+							hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
+							hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
+							hv = (1.0f < hv) ? 1.0f : hv;
+						}
+					}
+				}
+				for (; f < fe; f++) {
+					const uint32_t hc = (!SPARSE || ((m >> (f - f0)) & 1ull)) ? (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid] : 0u;
+					if (!((hv <= 0.01f) && (hc == 0))) {
+						const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
+						hv = (hv - de.x) * de.y + de.x;
+						hv = (hv < 0.0f) ? 0.0f : hv;
 						hv = (1.0f < hv) ? 1.0f : hv;
 					}
 				}
-				last = hc[7];
-			}
-			for (; f < p.n_batches; f++) {
-				const uint32_t hc = p.hc16[(size_t)f * cells + gid];
-				if (!((hv <= 0.01f) && (hc == 0))) {
-					const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
-					hv = (hv - de.x) * de.y + de.x;
-					hv = (hv < 0.0f) ? 0.0f : hv;
-					hv = (1.0f < hv) ? 1.0f : hv;
-				}
-				last = hc;
 			}
 			if (__float_as_uint(hv) != __float_as_uint(hv0))
 				p.hist[hidx] = hv;	/* cold cells (display.cl:237-238) keep their line clean */
-			if (p.hc_export)
-				p.hc_export[hidx] = last;	/* uint32 [bin][x] view of the last batch (fosphor_amd_buffers);
-								 * large states: made on demand by k_export_hc16 instead */
+			const bool now_hot = SPARSE && __ballot(!(hv <= 0.01f)) != 0;
+			if (SPARSE && lane == 0 && (p.hot_all || now_hot != was_hot))
+				p.hot[row] = now_hot ? 1 : 0;
+			}
 		}
 	}
 	if (MODE == 0 || MODE == 3) {
@@ -2967,8 +3011,12 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 	const int threads = p.n_bins * p.n + p.n;
 	int blocks = (threads + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	if (p.hc16 && p.batch <= 1024)
+	if (p.hc16 && p.batch <= 1024 && p.rowmask)
+		hipLaunchKernelGGL((k3_merge<0, true>), dim3(blocks), dim3(256), 0, s, p);
+	else if (p.hc16 && p.batch <= 1024)
 		hipLaunchKernelGGL(k3_merge<0>, dim3(blocks), dim3(256), 0, s, p);
+	else if (p.hc16 && p.rowmask)
+		hipLaunchKernelGGL((k3_merge<3, true>), dim3(blocks), dim3(256), 0, s, p);
 	else if (p.hc16)
 		hipLaunchKernelGGL(k3_merge<3>, dim3(blocks), dim3(256), 0, s, p);
 	else if (p.rise)
@@ -3224,9 +3272,11 @@ __global__ void k_fill(float *dst, float value, size_t n)
 		dst[i] = value;
 }
 
-/* uint32 [bin][x] view of one batch of 16-bit slab-major counts (the layout K3 mode 0 / 3 reads) */
+/* uint32 [bin][x] view of one batch of 16-bit slab-major counts (the layout K3 mode 0 / 3 reads; rows K2 did not
+ * store -- clear bit in its row mask -- are zero) */
 __global__ __launch_bounds__(256)
-void k_export_hc16(const uint16_t *__restrict__ hc16, uint32_t *__restrict__ out, int n_bins, int n)
+void k_export_hc16(const uint16_t *__restrict__ hc16, const uint32_t *__restrict__ rowmask, int mask_words, int mask_stride,
+                   uint32_t *__restrict__ out, int n_bins, int n)
 {
 	const size_t cells = (size_t)n_bins * n;
 	for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < cells; gid += (size_t)gridDim.x * 256) {
@@ -3234,15 +3284,16 @@ void k_export_hc16(const uint16_t *__restrict__ hc16, uint32_t *__restrict__ out
 		const int rem = (int)(gid - (size_t)slab * n_bins * 64);
 		const int bin = rem >> 6;
 		const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
-		out[(size_t)bin * n + slab * 64 + col] = hc16[gid];
+		const bool stored = !rowmask || ((rowmask[((size_t)slab * mask_words + (bin >> 5)) * mask_stride] >> (bin & 31)) & 1u);
+		out[(size_t)bin * n + slab * 64 + col] = stored ? hc16[gid] : 0u;
 	}
 }
 
-hipError_t launch_export_hc16(const uint16_t *hc16, uint32_t *out, int n_bins, int n, hipStream_t s)
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s)
 {
 	size_t blocks = ((size_t)n_bins * n + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, out, n_bins, n);
+	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, rowmask, mask_words, mask_stride, out, n_bins, n);
 	return hipGetLastError();
 }
 

@@ -81,8 +81,9 @@ int fosphor_amd_finish(struct fosphor *self);
  *   histogram  float[n_bins][N]    row = dB bin (0 = bottom), x unshifted
  *   spectrum   float[2][N][2]      live then max-hold; (x, y) vertices,
  *                                  index = bin ^ N/2 (fft-shifted)
- *   hitcount   uint32[n_bins][N]   integer counts of the LAST batch processed (views of 32 MiB and more --
- *                                  N = 65536 -- are written by this call, which then waits for them)
+ *   hitcount   uint32[n_bins][N]   integer counts of the LAST batch processed (the pipeline hands 16-bit
+ *                                  counts from kernel to kernel; this view of them is written by this call,
+ *                                  which waits for it)
  * Pointers are device pointers.  histogram / spectrum / hitcount stay where they are until fosphor_release;
  * d_waterfall is one of two rings and must be re-queried after every process call (a call that rewrites
  * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering). */

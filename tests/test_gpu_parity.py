@@ -272,11 +272,12 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
 @pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"},
                                  {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K1": "7"}, {"FOSPHOR_AMD_K23": "1"},
                                  {"FOSPHOR_AMD_ALT": "0"}, {"FOSPHOR_AMD_TILE": "16"}, {"FOSPHOR_AMD_SUB_LOG2": "17"},
-                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"}])
+                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"},
+                                 {"FOSPHOR_AMD_ROWMASK": "1"}, {"FOSPHOR_AMD_ROWMASK": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"}])
 def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
     """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the K1 variants
     (two waves per spectrum; asm-prefetched, one or two spectra ahead; three waves per SIMD with the IQ landing in the
-    exchange slab by LDS-DMA), the fused count+merge kernel, the tile
+    exchange slab by LDS-DMA), the fused count+merge kernel, the sparse count hand-off (row masks + hot-row flags), the tile
     length, sub-launches of one batch on alternating FFT streams (with and without stream ordering against the
     caller) are scheduling choices: several back-to-back launches, then a switch to the sharded path and back,
     must leave exactly the state of the sequential reference calls."""
@@ -1033,7 +1034,7 @@ def _c5_outputs(f):
     return [canon_bits(f.waterfall), canon_bits(f.histogram), canon_bits(f.spectrum), f.hitcount.copy()]
 
 
-@pytest.mark.parametrize("tile", [None, "4"])
+@pytest.mark.parametrize("tile", [None, "4", "nomask"])
 def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
     """N = 65536: the fused two-stage kernel (clusters of 8 work-groups per XCD, intermediate spectrum resident in
     the XCD's L2) against the two-kernel form (FOSPHOR_AMD_K1H_FUSED=0): every output bit-identical, over calls
@@ -1042,10 +1043,13 @@ def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
     too, otherwise it is compared within the float tolerance.)"""
     torch = torch_cuda
     n, nb, rows = 65536, 512, 64
-    if tile:
+    monkeypatch.delenv("FOSPHOR_AMD_TILE", raising=False)
+    monkeypatch.delenv("FOSPHOR_AMD_ROWMASK", raising=False)
+    if tile == "nomask":
+        tile = None
+        monkeypatch.setenv("FOSPHOR_AMD_ROWMASK", "0")
+    elif tile:
         monkeypatch.setenv("FOSPHOR_AMD_TILE", tile)
-    else:
-        monkeypatch.delenv("FOSPHOR_AMD_TILE", raising=False)
     monkeypatch.delenv("FOSPHOR_AMD_K1H_FUSED", raising=False)
     fa = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=160, max_batches=4, iq_fp16=True)
     monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", "0")
