@@ -102,6 +102,8 @@ struct fosphor
 	hipEvent_t ev_k2_done[2];		/* K2 wrote hit-count set h */
 	hipEvent_t ev_h_free[2];		/* K3 finished reading hit-count set h */
 	hipEvent_t ev_k3_done;			/* orders K3s that are issued on different streams */
+	hipEvent_t ev_k1h_gate;			/* N = 65536, fused FFT kernel: the previous piece's merge kernel has finished */
+	int       k1h_gate_set;
 	hipStream_t last_k3_stream;
 	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
 	hipEvent_t ev_set_free[kSets];		/* K2 finished reading set pp */
@@ -115,6 +117,7 @@ struct fosphor
 	uint32_t *d_rowmask;			/* K2 -> K3: one bit per (batch, slab, bin row) "this row has counts and is stored"; 2 sets */
 	int       mask_words;			/* ceil(n_bins / 32) */
 	uint8_t  *d_hot;			/* [N/64][n_bins]: some cell of the row is above the fast-exit level (K3 maintains it) */
+	uint32_t *d_rowlist;			/* [1 + rows]: the live rows of a merge (sparse form) */
 	int       hot_valid;			/* 0 after anything but the 16-bit K3 wrote the histogram */
 	uint16_t *d_slab16;			/* per-chunk packed 16-bit count slabs of batches longer than 1024 spectra / of a shard */
 	int       slab_chunks;			/* capacity of d_slab16 in 1024-spectrum chunks */
@@ -267,8 +270,9 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_h_free[i]) (void)hipEventDestroy(self->ev_h_free[i]);
 	}
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
+	if (self->ev_k1h_gate) (void)hipEventDestroy(self->ev_k1h_gate);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
-	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot);
+	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -395,8 +399,11 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
 	if (self->log2n == 16) {
+		/* Opt-in: alone the fused kernel beats the two-kernel form (350 us per 1024-spectrum frame against 376 with two
+		 * frames overlapping, 461 without) and moves 2.6 x less through the fabric, but it cannot share a CU with the
+		 * count kernel and the whole path ends up 3 % behind (131 against 135 GSamples/s), DESIGN.md section 8 */
 		const char *e = getenv("FOSPHOR_AMD_K1H_FUSED");
-		self->k1h_fused = !(e && *e == '0');
+		self->k1h_fused = (e && *e == '1');
 		/* two kernels: the whole launch's intermediate; fused: 512 KiB per cluster (kept at 64 clusters' worth) */
 		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)(self->max_spectra < 64 ? 64 : self->max_spectra) * self->n), "alloc stage scratch");
 		HIP_TRY(hipMalloc((void **)&self->d_k1h_sync, sizeof(uint32_t) * 64 * 64), "alloc cluster counters");
@@ -413,6 +420,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipEventCreateWithFlags(&self->ev_k3_done, dep_event_flags()), "create event");
+	HIP_TRY(hipEventCreateWithFlags(&self->ev_k1h_gate, dep_event_flags()), "create event");
 	if (getenv("FOSPHOR_AMD_K1_TIMING")) {
 		HIP_TRY(hipMalloc((void **)&self->d_dbg, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "alloc timing buffer");
 		HIP_TRY(hipMemset(self->d_dbg, 0, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "clear timing buffer");
@@ -445,6 +453,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_rowmask, sizeof(uint32_t) * 2 * (size_t)self->max_batches * (self->n / 64) * self->mask_words), "alloc row masks");
 	HIP_TRY(hipMalloc((void **)&self->d_hot, (size_t)(self->n / 64) * self->n_bins), "alloc row flags");
 	HIP_TRY(hipMemset(self->d_hot, 1, (size_t)(self->n / 64) * self->n_bins), "set row flags");
+	HIP_TRY(hipMalloc((void **)&self->d_rowlist, sizeof(uint32_t) * (1 + (size_t)(self->n / 64) * self->n_bins)), "alloc row list");
 	self->hot_valid = 0;
 	if (self->max_spectra > 1024) {
 		/* one slab per 1024-spectrum chunk of the largest launch: a whole shard (accumulate) or a sub-launch */
@@ -713,14 +722,14 @@ static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
 	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !getenv("FOSPHOR_AMD_NO_BIGCHUNK");
 }
 
-/* Sparse K2 -> K3 hand-off (row masks + hot flags): pays where the state is large (N = 8192: 16 MiB, N = 65536:
- * 128 MiB -- K3 then reads the 1 row in 5 that is alive instead of everything); at N = 1024 K3 is bound by its
- * 64-batch dependent chain, not by the rows it touches, and K2's mask costs more than K3 saves (measured -1 %).
+/* Sparse K2 -> K3 hand-off (row masks + hot flags): pays where the state is large and one batch is a whole frame
+ * (N = 65536: 128 MiB of state, +10 % for the path); at N = 1024 K3 is bound by its 64-batch dependent chain, not by the
+ * rows it touches, and K2's mask costs more than K3 saves (measured -1 %; N = 8192: -2.5 %).
  * FOSPHOR_AMD_ROWMASK=0 / 1 forces it off / on. */
 static int use_rowmask(const struct fosphor *self)
 {
 	const char *e = getenv("FOSPHOR_AMD_ROWMASK");
-	return e ? (*e != '0') : self->log2n != 10;
+	return e ? (*e != '0') : self->log2n == 16;
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -843,6 +852,7 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 			k3.mask_stride = self->max_batches;
 			self->export_mask = k3.rowmask + (n_batches - 1);
 			k3.hot = self->d_hot;
+			k3.rowlist = self->d_rowlist;
 			k3.hot_all = !self->hot_valid;
 			self->hot_valid = 1;
 		} else {
@@ -1002,6 +1012,14 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		self->d_partial = self->d_partial_pp[set];
 		if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
 			HIP_TRY(hipStreamWaitEvent(ks, self->ev_set_free[set], 0), "wait for intermediate set");
+		if (self->overlap && self->log2n == 16 && self->k1h_fused && self->k1h_gate_set) {
+			/* The fused FFT kernel fills every CU's LDS for its whole run.  Count / merge kernels that reach the CUs
+			 * first keep its work-groups out (they need a nearly empty CU) while it already spins for its clusters,
+			 * and both crawl (measured 445 us for the FFT kernel instead of 350); a merge kernel held to 64 registers
+			 * so that it fits beside the FFT kernel's waves costs the FFT kernel as much as it hides (470-500 us).
+			 * The FFT kernel therefore starts when the previous piece's merge has finished. */
+			HIP_TRY(hipStreamWaitEvent(ks, self->ev_k1h_gate, 0), "FFT waits for the previous merge kernel");
+		}
 
 		wf_first = wf_first_global - t0;
 		if (wf_first < 0) wf_first = 0;
@@ -1059,6 +1077,10 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		}
 		if (!(dbg_skip & 4) && run_merge(self, nb, batch, 0, st3, 1, hset))
 			return -EIO;
+		if (self->overlap && self->log2n == 16 && self->k1h_fused) {
+			HIP_TRY(hipEventRecord(self->ev_k1h_gate, st3), "record merge done");
+			self->k1h_gate_set = 1;
+		}
 		if (three) {
 			HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
 			self->hset_used[hset] = 1;

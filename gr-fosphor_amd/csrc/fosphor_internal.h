@@ -126,6 +126,7 @@ struct K3Params {
 					 * (display.cl:237)", maintained here; a row that is not hot and has no count in any batch of
 					 * the launch is skipped without reading its cells */
 	int   hot_all;			/* the flags are stale (another kernel wrote the histogram): visit every row, rewrite them */
+	uint32_t *rowlist;		/* sparse form: [1 + rows] count, then the live rows (k3_scan writes, k3_merge reads) */
 };
 
 /* K23: hit counts AND state update in one kernel (N = 1024 path, 8-bit bin indices, batch <= 1024).

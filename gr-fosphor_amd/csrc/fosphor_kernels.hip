@@ -2853,6 +2853,106 @@ void k3_merge(const K3Params p)
 		__syncthreads();
 	}
 
+	/* one column: live EMA (display.cl:186-214) and max-hold (display.cl:257-310) */
+	auto update_column = [&](const int x) {
+		const int half = p.n >> 1;
+		const int i = x ^ half;
+		const float decay = p.live_decay;
+		float live = p.spectrum[i].y;
+		float mh   = p.spectrum[p.n + i].y;
+		for (int f = 0; f < p.n_batches; f++) {
+			const float sum = p.live_sum[(size_t)f * p.n + x];
+			const float mx  = p.vmax[(size_t)f * p.n + x];
+			if (!__builtin_isfinite(live))
+				live = sum / 16.0f;			/* display.cl:206-207 */
+			live = live * decay + sum * p.alpha;		/* display.cl:210-211 */
+			if (!__builtin_isfinite(mh))
+				mh = -3.402823466e+38f;			/* display.cl:290-291 */
+			mh = mh * 0.999f + 0.001f * live;		/* display.cl:303 */
+			mh = (mh < mx) ? mx : mh;			/* display.cl:304-305 */
+		}
+		const float vx = ((float)i / (float)half) - 1.0f;	/* display.cl:209,293 */
+		p.spectrum[i]      = make_float2(vx, live);
+		p.spectrum[p.n + i] = make_float2(vx, mh);
+	};
+
+	if (SPARSE) {
+		/* Sparse form: k3_scan has listed the rows that are alive (hot, or with a count in some batch of the launch);
+		 * a wave takes every n_waves-th entry of the list, its 64 lanes are the row's 64 cells.  A cold, empty row
+		 * costs one byte of flag and a few mask bits in the scan and nothing here. */
+		const int lane = threadIdx.x & 63;
+		const int nb = p.n_bins;
+		const int n_waves = gridDim.x * 4;
+		const int count = (int)p.rowlist[0];
+		const int col = (lane >> 1) + ((lane & 1) << 5);
+		constexpr int R = 4;			/* rows in flight per wave: every step below is R independent requests */
+		for (int idx0 = (blockIdx.x * 256 + threadIdx.x) >> 6; idx0 < count; idx0 += R * n_waves) {
+			uint32_t e[R];
+			int slab[R], bin[R], hidx[R], gid[R];
+			float hv0[R], hv[R];
+			bool valid[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				valid[r] = idx0 + r * n_waves < count;		/* uniform */
+				e[r] = valid[r] ? p.rowlist[1 + idx0 + r * n_waves] : 0u;
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const int row = (int)(e[r] & 0x7fffffffu);
+				slab[r] = row / nb; bin[r] = row - slab[r] * nb;
+				gid[r] = row * 64 + lane;
+				hidx[r] = bin[r] * p.n + slab[r] * 64 + col;
+				hv0[r] = valid[r] ? p.hist[hidx[r]] : 0.0f;
+				hv[r] = hv0[r];
+			}
+			for (int f0 = 0; f0 < p.n_batches; f0 += 64) {
+				unsigned long long m[R];
+				const int fl = f0 + lane;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					const uint32_t wd = (valid[r] && fl < p.n_batches)
+					        ? p.rowmask[((size_t)slab[r] * p.mask_words + (bin[r] >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
+					m[r] = __ballot((wd >> (bin[r] & 31)) & 1u);
+				}
+				const int fe = (p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
+				for (int f = f0; f < fe; f += 8) {
+					uint32_t hc[R][8];
+#pragma unroll
+					for (int r = 0; r < R; r++)
+#pragma unroll
+						for (int u = 0; u < 8; u++)
+							hc[r][u] = (f + u < fe && ((m[r] >> (f + u - f0)) & 1ull))
+							        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid[r]]) : 0u;
+#pragma unroll
+					for (int r = 0; r < R; r++)
+#pragma unroll
+						for (int u = 0; u < 8; u++) {
+							if (f + u < fe && !((hv[r] <= 0.01f) && (hc[r][u] == 0))) {	/* display.cl:237-238 */
+								const float2 de = (MODE == 0) ? rise_lds[hc[r][u]] : p.rise[hc[r][u]];
+								hv[r] = (hv[r] - de.x) * de.y + de.x;		/* display.cl:247 */
+								hv[r] = (hv[r] < 0.0f) ? 0.0f : hv[r];		/* clamp, display.cl:250 */
+								hv[r] = (1.0f < hv[r]) ? 1.0f : hv[r];
+							}
+						}
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (!valid[r])
+					continue;
+				if (__float_as_uint(hv[r]) != __float_as_uint(hv0[r]))
+					p.hist[hidx[r]] = hv[r];	/* cold cells (display.cl:237-238) keep their line clean */
+				const bool was_hot = (e[r] >> 31) != 0;
+				const bool now_hot = __ballot(!(hv[r] <= 0.01f)) != 0;
+				if (lane == 0 && (p.hot_all || now_hot != was_hot))
+					p.hot[e[r] & 0x7fffffffu] = now_hot ? 1 : 0;
+			}
+		}
+		for (int x = blockIdx.x * 256 + threadIdx.x; x < p.n; x += gridDim.x * 256)
+			update_column(x);
+		return;
+	}
+
 	for (int gid = blockIdx.x * 256 + threadIdx.x; gid < cells + p.n; gid += gridDim.x * 256) {
 	if (MODE == 0 || MODE == 3) {
 		/* 16-bit slab-major counts as K2 leaves them ([slab of 64 columns][bin][32] dwords, columns
@@ -2866,38 +2966,16 @@ void k3_merge(const K3Params p)
 			const int bin = rem >> 6;
 			const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
 			const int hidx = bin * p.n + slab * 64 + col;
-			const int row = slab * nb + bin;			/* one wave = the 64 cells of one (slab, bin) row */
-			const int lane = threadIdx.x & 63;
-			/* K2's row bits of every batch of the launch for this row: lane l asks for batch f0 + l */
-			const bool was_hot = !SPARSE || p.hot_all || p.hot[row] != 0;
-			bool any = was_hot;
-			if (SPARSE && !any) {
-				for (int f0 = 0; f0 < p.n_batches && !any; f0 += 64) {
-					const int fl = f0 + lane;
-					const uint32_t wd = (fl < p.n_batches)
-					        ? p.rowmask[((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
-					any = __ballot((wd >> (bin & 31)) & 1u) != 0;
-				}
-			}
-			if (!SPARSE || any) {
 			const float hv0 = p.hist[hidx];
 			float hv = hv0;
-			for (int f0 = 0; f0 < p.n_batches; f0 += (SPARSE ? 64 : p.n_batches)) {
-				unsigned long long m = ~0ull;
-				if (SPARSE) {
-					const int fl = f0 + lane;
-					const uint32_t wd = (fl < p.n_batches)
-					        ? p.rowmask[((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
-					m = __ballot((wd >> (bin & 31)) & 1u);
-				}
-				const int fe = (!SPARSE || p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
-				int f = f0;
+			{
+				const int fe = p.n_batches;
+				int f = 0;
 				for (; f + 8 <= fe; f += 8) {
 					uint32_t hc[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++)
-						hc[u] = (!SPARSE || ((m >> (f + u - f0)) & 1ull))
-						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]) : 0u;
+						hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
@@ -2909,7 +2987,7 @@ void k3_merge(const K3Params p)
 					}
 				}
 				for (; f < fe; f++) {
-					const uint32_t hc = (!SPARSE || ((m >> (f - f0)) & 1ull)) ? (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid] : 0u;
+					const uint32_t hc = p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid];
 					if (!((hv <= 0.01f) && (hc == 0))) {
 						const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
 						hv = (hv - de.x) * de.y + de.x;
@@ -2920,10 +2998,6 @@ void k3_merge(const K3Params p)
 			}
 			if (__float_as_uint(hv) != __float_as_uint(hv0))
 				p.hist[hidx] = hv;	/* cold cells (display.cl:237-238) keep their line clean */
-			const bool now_hot = SPARSE && __ballot(!(hv <= 0.01f)) != 0;
-			if (SPARSE && lane == 0 && (p.hot_all || now_hot != was_hot))
-				p.hot[row] = now_hot ? 1 : 0;
-			}
 		}
 	}
 	if (MODE == 0 || MODE == 3) {
@@ -2980,30 +3054,64 @@ void k3_merge(const K3Params p)
 		}
 		p.hist[gid] = hv;
 	}
-	if (gid >= cells && gid < cells + p.n) {
-		/* one column: live EMA (display.cl:186-214) and max-hold (display.cl:257-310) */
-		const int x = gid - cells;
-		const int half = p.n >> 1;
-		const int i = x ^ half;
-		const float decay = p.live_decay;
-		float live = p.spectrum[i].y;
-		float mh   = p.spectrum[p.n + i].y;
-		for (int f = 0; f < p.n_batches; f++) {
-			const float sum = p.live_sum[(size_t)f * p.n + x];
-			const float mx  = p.vmax[(size_t)f * p.n + x];
-			if (!__builtin_isfinite(live))
-				live = sum / 16.0f;			/* display.cl:206-207 */
-			live = live * decay + sum * p.alpha;		/* display.cl:210-211 */
-			if (!__builtin_isfinite(mh))
-				mh = -3.402823466e+38f;			/* display.cl:290-291 */
-			mh = mh * 0.999f + 0.001f * live;		/* display.cl:303 */
-			mh = (mh < mx) ? mx : mh;			/* display.cl:304-305 */
-		}
-		const float vx = ((float)i / (float)half) - 1.0f;	/* display.cl:209,293 */
-		p.spectrum[i]      = make_float2(vx, live);
-		p.spectrum[p.n + i] = make_float2(vx, mh);
-	}
+	if (gid >= cells && gid < cells + p.n)
+		update_column(gid - cells);
 	}	/* cell loop */
+}
+
+/* Sparse form, first step: the list of live rows.  rowlist[0] = count (zeroed by the host), rowlist[1 + i] = row
+ * index, bit 31 = the row's hot flag as stored. */
+__global__ __launch_bounds__(1024)
+void k3_scan(const K3Params p)
+{
+	constexpr int RPT = 4;				/* rows per thread: 4096 rows and ONE atomic on the shared counter per block */
+	__shared__ uint32_t wave_cnt[16], wave_base[16];
+	const int rows = p.n_bins * (p.n >> 6);
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int row0 = blockIdx.x * (1024 * RPT) + threadIdx.x;
+	bool hot[RPT], act[RPT];
+	uint32_t mine = 0;
+#pragma unroll
+	for (int k = 0; k < RPT; k++) {
+		const int row = row0 + 1024 * k;
+		hot[k] = (row < rows) && p.hot[row] != 0;
+		act[k] = (row < rows) && (hot[k] || p.hot_all);
+	}
+#pragma unroll
+	for (int k = 0; k < RPT; k++) {
+		const int row = row0 + 1024 * k;
+		if (row < rows && !act[k]) {
+			const int slab = row / p.n_bins, bin = row - slab * p.n_bins;
+			const uint32_t *mw = p.rowmask + ((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride;
+			uint32_t acc = 0;
+			for (int f = 0; f < p.n_batches; f++)
+				acc |= mw[p.dbg_same ? 0 : f];
+			act[k] = (acc >> (bin & 31)) & 1u;
+		}
+		mine += act[k] ? 1u : 0u;
+	}
+	/* wave prefix of `mine`, then the waves' totals through LDS */
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(incl, d, 64);
+		if (lane >= d) incl += o;
+	}
+	if (lane == 63)
+		wave_cnt[wv] = incl;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (int w = 0; w < 16; w++) { wave_base[w] = tot; tot += wave_cnt[w]; }
+		const uint32_t base = tot ? atomicAdd(&p.rowlist[0], tot) : 0u;
+		for (int w = 0; w < 16; w++) wave_base[w] += base;
+	}
+	__syncthreads();
+	uint32_t pos = wave_base[wv] + incl - mine;
+#pragma unroll
+	for (int k = 0; k < RPT; k++)
+		if (act[k])
+			p.rowlist[1 + pos++] = (uint32_t)(row0 + 1024 * k) | (hot[k] ? 0x80000000u : 0u);
 }
 
 hipError_t launch_k3(const K3Params &p, hipStream_t s)
@@ -3011,12 +3119,22 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 	const int threads = p.n_bins * p.n + p.n;
 	int blocks = (threads + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	if (p.hc16 && p.batch <= 1024 && p.rowmask)
-		hipLaunchKernelGGL((k3_merge<0, true>), dim3(blocks), dim3(256), 0, s, p);
-	else if (p.hc16 && p.batch <= 1024)
+	if (p.hc16 && p.rowmask) {
+		/* sparse form: list the live rows, then one wave per listed row (strided) */
+		const int rows = p.n_bins * (p.n / 64);
+		if (hipMemsetAsync(p.rowlist, 0, sizeof(uint32_t), s) != hipSuccess)
+			return hipErrorLaunchFailure;
+		hipLaunchKernelGGL(k3_scan, dim3((rows + 4095) / 4096), dim3(1024), 0, s, p);
+		int sb = (rows + 15) / 16;			/* 4 waves x 4 rows in flight per block; the list is usually far shorter */
+		if (sb > 2048) sb = 2048;
+		if (p.batch <= 1024)
+			hipLaunchKernelGGL((k3_merge<0, true>), dim3(sb), dim3(256), 0, s, p);
+		else
+			hipLaunchKernelGGL((k3_merge<3, true>), dim3(sb), dim3(256), 0, s, p);
+		return hipGetLastError();
+	}
+	if (p.hc16 && p.batch <= 1024)
 		hipLaunchKernelGGL(k3_merge<0>, dim3(blocks), dim3(256), 0, s, p);
-	else if (p.hc16 && p.rowmask)
-		hipLaunchKernelGGL((k3_merge<3, true>), dim3(blocks), dim3(256), 0, s, p);
 	else if (p.hc16)
 		hipLaunchKernelGGL(k3_merge<3>, dim3(blocks), dim3(256), 0, s, p);
 	else if (p.rise)

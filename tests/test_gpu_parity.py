@@ -928,9 +928,11 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built):
     f.close()
 
 
-def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_fft65536_bit_exact(amd, torch_cuda, oracle_built, monkeypatch, fused):
     """N = 65536 in two LDS stages (passes 1-3 per residue mod 128, passes 4-5 + radix 2 per offset mod 512):
     the bits of the oracle's 8.8.8.8.8.2 plan, fp32 and fp16 input."""
+    monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", fused)		# two kernels (default) / both stages in one kernel
     torch = torch_cuda
     n = 65536
     o = Oracle(fft_len_log=16, n_bins=512, wf_rows=64)
@@ -960,9 +962,11 @@ def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
     fh.close()
 
 
-def test_c5_geometry_vs_oracle(amd, torch_cuda, oracle_built):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_c5_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, fused):
     """BASELINE config C5 on one GPU: 65536-point FFT, fp16 IQ, 512 bins; two launches with state
     carry-over, then the host path.  The oracle gets the same fp16 values widened to fp32."""
+    monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", fused)
     torch = torch_cuda
     n, nb, rows = 65536, 512, 64
     f = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=64, iq_fp16=True)
@@ -1037,7 +1041,7 @@ def _c5_outputs(f):
 @pytest.mark.parametrize("tile", [None, "4", "nomask"])
 def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
     """N = 65536: the fused two-stage kernel (clusters of 8 work-groups per XCD, intermediate spectrum resident in
-    the XCD's L2) against the two-kernel form (FOSPHOR_AMD_K1H_FUSED=0): every output bit-identical, over calls
+    the XCD's L2, FOSPHOR_AMD_K1H_FUSED=1) against the default two-kernel form: every output bit-identical, over calls
     whose tile counts do not divide evenly among the clusters, multi-batch calls and a ring wrap.  (The two forms
     pick different tile lengths for the live partials; with the same length forced the live spectrum is bit-identical
     too, otherwise it is compared within the float tolerance.)"""
@@ -1050,7 +1054,7 @@ def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
         monkeypatch.setenv("FOSPHOR_AMD_ROWMASK", "0")
     elif tile:
         monkeypatch.setenv("FOSPHOR_AMD_TILE", tile)
-    monkeypatch.delenv("FOSPHOR_AMD_K1H_FUSED", raising=False)
+    monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", "1")
     fa = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=160, max_batches=4, iq_fp16=True)
     monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", "0")
     fb = amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=160, max_batches=4, iq_fp16=True)
@@ -1069,12 +1073,13 @@ def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
     fa.close(); fb.close()
 
 
-def test_c5_fused_instances_side_by_side(amd, torch_cuda):
+def test_c5_fused_instances_side_by_side(amd, torch_cuda, monkeypatch):
     """Three N = 65536 instances with work queued at the same time on their own streams: the clusters of the fused
     kernels form from whatever work-groups are resident (no kernel waits for a work-group that is not), all three
     finish and agree."""
     torch = torch_cuda
     n, nb, rows = 65536, 512, 64
+    monkeypatch.setenv("FOSPHOR_AMD_K1H_FUSED", "1")
     fs = [amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=128, iq_fp16=True) for _ in range(3)]
     x = add_tone(gaussian_iq(128 * n, 311), 0.05, 0.37).astype(np.float16)
     d = torch.from_numpy(x).cuda()

@@ -1,0 +1,10 @@
+#!/bin/bash
+out=gpurun_out/ab25; mkdir -p $out
+b() { label=$1; cfg=$2; shift; shift; env "$@" timeout 200 python3 bench.py --config $cfg --steps 100 --warmup 10 --no-cpu-baseline --no-traffic-twin --no-extra-passes 2>$out/$label.err | python3 tools/bline.py $label; }
+for rep in 1 2; do
+b c5_$rep C5 X=1
+b c5_t16_$rep C5 FOSPHOR_AMD_TILE=16
+b c5_t8_$rep C5 FOSPHOR_AMD_TILE=8
+b c5_two_$rep C5 FOSPHOR_AMD_K1H_FUSED=0
+b c5_k1only_$rep C5 FOSPHOR_AMD_DBG_SKIP=2
+done
