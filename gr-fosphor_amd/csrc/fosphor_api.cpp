@@ -399,11 +399,12 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
 	if (self->log2n == 16) {
-		/* Opt-in: alone the fused kernel beats the two-kernel form (350 us per 1024-spectrum frame against 376 with two
-		 * frames overlapping, 461 without) and moves 2.6 x less through the fabric, but it cannot share a CU with the
-		 * count kernel and the whole path ends up 3 % behind (131 against 135 GSamples/s), DESIGN.md section 8 */
+		/* Default: alone the fused kernel beats the two-kernel form (346 us per 1024-spectrum frame against 376 with two
+		 * frames overlapping, 461 without) and moves 1.7 x less through the fabric; it cannot share a CU with the count
+		 * kernel, so the whole path is level with the two-kernel form (133-137 against 134-135 GSamples/s),
+		 * DESIGN.md section 8.  FOSPHOR_AMD_K1H_FUSED=0: two kernels. */
 		const char *e = getenv("FOSPHOR_AMD_K1H_FUSED");
-		self->k1h_fused = (e && *e == '1');
+		self->k1h_fused = !(e && *e == '0');
 		/* two kernels: the whole launch's intermediate; fused: 512 KiB per cluster (kept at 64 clusters' worth) */
 		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)(self->max_spectra < 64 ? 64 : self->max_spectra) * self->n), "alloc stage scratch");
 		HIP_TRY(hipMalloc((void **)&self->d_k1h_sync, sizeof(uint32_t) * 64 * 64), "alloc cluster counters");

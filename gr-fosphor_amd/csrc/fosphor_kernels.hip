@@ -2837,6 +2837,12 @@ hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
  * (batches of up to 8192 spectra counted as one chunk); 1: 32-bit counts + (d, e) table in memory;
  * 2: 32-bit counts, (d, e) evaluated per cell (batches beyond the table).  Separate instantiations keep
  * the common one (0) at a register budget that lets it share a SIMD with K1. */
+#ifndef K3_ROWS
+#define K3_ROWS 8
+#endif
+#ifndef K3_BATCHES
+#define K3_BATCHES 2
+#endif
 template <int MODE, bool SPARSE = false>
 __global__ __launch_bounds__(256)
 void k3_merge(const K3Params p)
@@ -2885,7 +2891,8 @@ void k3_merge(const K3Params p)
 		const int n_waves = gridDim.x * 4;
 		const int count = (int)p.rowlist[0];
 		const int col = (lane >> 1) + ((lane & 1) << 5);
-		constexpr int R = 4;			/* rows in flight per wave: every step below is R independent requests */
+		constexpr int R = K3_ROWS;		/* rows in flight per wave: every step below is R independent requests */
+		constexpr int U = K3_BATCHES;		/* batches of counts in flight per row */
 		for (int idx0 = (blockIdx.x * 256 + threadIdx.x) >> 6; idx0 < count; idx0 += R * n_waves) {
 			uint32_t e[R];
 			int slab[R], bin[R], hidx[R], gid[R];
@@ -2915,18 +2922,18 @@ void k3_merge(const K3Params p)
 					m[r] = __ballot((wd >> (bin[r] & 31)) & 1u);
 				}
 				const int fe = (p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
-				for (int f = f0; f < fe; f += 8) {
-					uint32_t hc[R][8];
+				for (int f = f0; f < fe; f += U) {
+					uint32_t hc[R][U];
 #pragma unroll
 					for (int r = 0; r < R; r++)
 #pragma unroll
-						for (int u = 0; u < 8; u++)
+						for (int u = 0; u < U; u++)
 							hc[r][u] = (f + u < fe && ((m[r] >> (f + u - f0)) & 1ull))
 							        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid[r]]) : 0u;
 #pragma unroll
 					for (int r = 0; r < R; r++)
 #pragma unroll
-						for (int u = 0; u < 8; u++) {
+						for (int u = 0; u < U; u++) {
 							if (f + u < fe && !((hv[r] <= 0.01f) && (hc[r][u] == 0))) {	/* display.cl:237-238 */
 								const float2 de = (MODE == 0) ? rise_lds[hc[r][u]] : p.rise[hc[r][u]];
 								hv[r] = (hv[r] - de.x) * de.y + de.x;		/* display.cl:247 */
@@ -3125,7 +3132,7 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 		if (hipMemsetAsync(p.rowlist, 0, sizeof(uint32_t), s) != hipSuccess)
 			return hipErrorLaunchFailure;
 		hipLaunchKernelGGL(k3_scan, dim3((rows + 4095) / 4096), dim3(1024), 0, s, p);
-		int sb = (rows + 15) / 16;			/* 4 waves x 4 rows in flight per block; the list is usually far shorter */
+		int sb = (rows + 4 * K3_ROWS - 1) / (4 * K3_ROWS);	/* 4 waves x K3_ROWS rows in flight per block; the list is usually far shorter */
 		if (sb > 2048) sb = 2048;
 		if (p.batch <= 1024)
 			hipLaunchKernelGGL((k3_merge<0, true>), dim3(sb), dim3(256), 0, s, p);

@@ -1041,7 +1041,7 @@ def _c5_outputs(f):
 @pytest.mark.parametrize("tile", [None, "4", "nomask"])
 def test_c5_fused_equals_two_kernel_form(amd, torch_cuda, monkeypatch, tile):
     """N = 65536: the fused two-stage kernel (clusters of 8 work-groups per XCD, intermediate spectrum resident in
-    the XCD's L2, FOSPHOR_AMD_K1H_FUSED=1) against the default two-kernel form: every output bit-identical, over calls
+    the XCD's L2; the default) against the two-kernel form (FOSPHOR_AMD_K1H_FUSED=0): every output bit-identical, over calls
     whose tile counts do not divide evenly among the clusters, multi-batch calls and a ring wrap.  (The two forms
     pick different tile lengths for the live partials; with the same length forced the live spectrum is bit-identical
     too, otherwise it is compared within the float tolerance.)"""
