@@ -240,13 +240,16 @@ struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
  * +inf for |X|^2 in {0, denormal-flushed, inf}, NaN for NaN: compared as an unsigned bit
  * pattern all of those order above every finite value, so one running v_max_u32 per spectrum
  * collects "some sample needs the exact path" without per-sample compares or branches. */
+#ifndef K1_DBG_EPI
+#define K1_DBG_EPI 0		/* measurement only (wrong results): 1 no v_log_f32, 2 no ambiguity measure, 4 no live / max update, 8 no bin byte */
+#endif
 static __device__ __forceinline__ float bin_fast(float re, float im, const BinConst &k, float *l2_out, uint32_t *amb_bits)
 {
 	const float s  = __builtin_fmaf(re, re, im * im);
-	const float l2 = __builtin_amdgcn_logf(s);		/* v_log_f32 */
+	const float l2 = (K1_DBG_EPI & 1) ? s : __builtin_amdgcn_logf(s);		/* v_log_f32 */
 	const float v  = __builtin_fmaf(k.A, l2, k.C);
 	const float r  = __builtin_rintf(v);
-	const float a  = __builtin_fmaf(__builtin_fabsf(l2), k.kappa, __builtin_fabsf(v - r));
+	const float a  = (K1_DBG_EPI & 2) ? 0.0f : __builtin_fmaf(__builtin_fabsf(l2), k.kappa, __builtin_fabsf(v - r));
 	*l2_out = l2;
 	*amb_bits = __float_as_uint(a);
 	return r;
@@ -578,7 +581,10 @@ void k1_fft_bin(const K1Params p)
 				uint32_t ab;
 				const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
 				amb = amb > ab ? amb : ab;			/* v_max_u32: NaN / inf propagate */
-				pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+				if (!(K1_DBG_EPI & 8))
+					pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+				else
+					pack[m] ^= __float_as_uint(r);
 			}
 #ifndef K1_DBG_NO_EXACT
 #define K1_DBG_NO_EXACT 0		/* measurement only: 1 drops the exact path (wrong bins on near-ties) */
@@ -606,6 +612,7 @@ void k1_fft_bin(const K1Params p)
 			for (int m = 0; m < 16; m++) {
 				/* Horner form of display.cl:149-150, in place (v_fma with the accumulator as destination:
 				 * the compiler's v_fmac into the dying l2 register costs a v_mov per column) */
+				if (K1_DBG_EPI & 4) { live[m] = l2[m]; continue; }
 				asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
 				vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
 			}
