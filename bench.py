@@ -48,6 +48,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0		# MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+ACHIEVABLE_GBS = 6290.0		# measured float4 copy on MI355X (guide), informational
 
 # name -> geometry.  spb = spectra per batch, bps = default batches per step, over = overlap_cc ratio
 CONFIGS = {
@@ -344,6 +345,9 @@ def main():
                                        "hipEvent intervals); *_plain_average divides by the mean individual duration, which counts "
                                        "the shared time twice",
                          "whole_path_frac": value * 1e6 * bytes_per_sample / 1e9 / HBM_PEAK_GBS / max(1, world),
+                         # also against what the part delivers (6.29 TB/s float4 copy, MI355X_MICROARCH.md)
+                         "frac_of_achievable": achieved / ACHIEVABLE_GBS,
+                         "k1_traffic_rate_GBs": (traffic / 1e9 / (k1_busy * 1e-3)) if (traffic and k1_busy > 0) else None,
                          "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
                          "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
                          "algorithmic_bytes_per_launch": alg_bytes,
