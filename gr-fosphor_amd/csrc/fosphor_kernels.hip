@@ -2912,7 +2912,7 @@ void k3_merge(const K3Params p)
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				const int row = (int)(e[r] & 0x7fffffffu);
+				const int row = (int)(e[r] & 0xfffffu);
 				slab[r] = row / nb; bin[r] = row - slab[r] * nb;
 				gid[r] = row * 64 + lane;
 				hidx[r] = bin[r] * p.n + slab[r] * 64 + col;
@@ -2922,11 +2922,17 @@ void k3_merge(const K3Params p)
 			for (int f0 = 0; f0 < p.n_batches; f0 += 64) {
 				unsigned long long m[R];
 				const int fl = f0 + lane;
+				if (p.n_batches <= 11) {
 #pragma unroll
-				for (int r = 0; r < R; r++) {
-					const uint32_t wd = (valid[r] && fl < p.n_batches)
-					        ? p.rowmask[((size_t)slab[r] * p.mask_words + (bin[r] >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
-					m[r] = __ballot((wd >> (bin[r] & 31)) & 1u);
+					for (int r = 0; r < R; r++)
+						m[r] = (e[r] >> 20) & 0x7ffu;		/* carried by the list entry */
+				} else {
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						const uint32_t wd = (valid[r] && fl < p.n_batches)
+						        ? p.rowmask[((size_t)slab[r] * p.mask_words + (bin[r] >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
+						m[r] = __ballot((wd >> (bin[r] & 31)) & 1u);
+					}
 				}
 				const int fe = (p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
 				for (int f = f0; f < fe; f += U) {
@@ -2959,7 +2965,7 @@ void k3_merge(const K3Params p)
 				const bool was_hot = (e[r] >> 31) != 0;
 				const bool now_hot = __ballot(!(hv[r] <= 0.01f)) != 0;
 				if (lane == 0 && (p.hot_all || now_hot != was_hot))
-					p.hot[e[r] & 0x7fffffffu] = now_hot ? 1 : 0;
+					p.hot[e[r] & 0xfffffu] = now_hot ? 1 : 0;
 			}
 		}
 		for (int x = blockIdx.x * 256 + threadIdx.x; x < p.n; x += gridDim.x * 256)
@@ -3074,7 +3080,8 @@ void k3_merge(const K3Params p)
 }
 
 /* Sparse form, first step: the list of live rows.  rowlist[0] = count (zeroed by the host), rowlist[1 + i] = row
- * index, bit 31 = the row's hot flag as stored. */
+ * index (20 bits), bits 20-30 = which batches have counts in the row (launches of <= 11 batches), bit 31 = the row's hot
+ * flag as stored. */
 __global__ __launch_bounds__(1024)
 void k3_scan(const K3Params p)
 {
@@ -3084,23 +3091,30 @@ void k3_scan(const K3Params p)
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int row0 = blockIdx.x * (1024 * RPT) + threadIdx.x;
 	bool hot[RPT], act[RPT];
+	uint32_t bits[RPT];			/* bit f: batch f of the launch has counts in this row (launches of <= 11 batches) */
 	uint32_t mine = 0;
+	const bool carry = p.n_batches <= 11;	/* ... then the list entry carries them and k3_merge needs no mask request */
 #pragma unroll
 	for (int k = 0; k < RPT; k++) {
 		const int row = row0 + 1024 * k;
 		hot[k] = (row < rows) && p.hot[row] != 0;
 		act[k] = (row < rows) && (hot[k] || p.hot_all);
+		bits[k] = 0;
 	}
 #pragma unroll
 	for (int k = 0; k < RPT; k++) {
 		const int row = row0 + 1024 * k;
-		if (row < rows && !act[k]) {
+		if (row < rows && (carry || !act[k])) {
 			const int slab = row / p.n_bins, bin = row - slab * p.n_bins;
 			const uint32_t *mw = p.rowmask + ((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride;
-			uint32_t acc = 0;
-			for (int f = 0; f < p.n_batches; f++)
-				acc |= mw[p.dbg_same ? 0 : f];
-			act[k] = (acc >> (bin & 31)) & 1u;
+			uint32_t any = 0;
+			for (int f = 0; f < p.n_batches; f++) {
+				const uint32_t b = (mw[p.dbg_same ? 0 : f] >> (bin & 31)) & 1u;
+				any |= b;
+				if (carry)
+					bits[k] |= b << f;
+			}
+			act[k] = act[k] || any;
 		}
 		mine += act[k] ? 1u : 0u;
 	}
@@ -3125,7 +3139,7 @@ void k3_scan(const K3Params p)
 #pragma unroll
 	for (int k = 0; k < RPT; k++)
 		if (act[k])
-			p.rowlist[1 + pos++] = (uint32_t)(row0 + 1024 * k) | (hot[k] ? 0x80000000u : 0u);
+			p.rowlist[1 + pos++] = (uint32_t)(row0 + 1024 * k) | (bits[k] << 20) | (hot[k] ? 0x80000000u : 0u);
 }
 
 hipError_t launch_k3(const K3Params &p, hipStream_t s)
@@ -3133,7 +3147,7 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 	const int threads = p.n_bins * p.n + p.n;
 	int blocks = (threads + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	if (p.hc16 && p.rowmask) {
+	if (p.hc16 && p.rowmask && p.n_bins * (p.n / 64) <= (1 << 20)) {	/* (list entries hold 20 bits of row index: every geometry the library accepts) */
 		/* sparse form: list the live rows, then one wave per listed row (strided) */
 		const int rows = p.n_bins * (p.n / 64);
 		if (hipMemsetAsync(p.rowlist, 0, sizeof(uint32_t), s) != hipSuccess)
