@@ -2378,7 +2378,7 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
 		attr_set = true;
 	}
-	if (p0.sync) {
+	if (p0.sync && p0.tile >= 2 && !(p0.tile & 1) && p0.total / p0.tile < (1 << 20)) {	/* (tile index: 20 bits of the claim word) */
 		/* fused form: 32 clusters of 8 work-groups, one work-group per CU */
 		constexpr size_t lds_f = ((size_t)16 * 513 + (8 + 64) * 7 + 7 * 64 + 8 * 7 * 64 + 64 * 64) * sizeof(float2);
 		static bool attr_f = false;
