@@ -1217,8 +1217,9 @@ extern "C" int fosphor_amd_finish(struct fosphor *self)
 	if (sync_all(self))
 		return -EIO;
 	if (self->h_k1h_err && self->h_k1h_err[0]) {
-		fprintf(stderr, "[fosphor_amd] fused 65536-point FFT: work-group %u is not on the XCD its cluster expects; "
-		        "results are invalid (set FOSPHOR_AMD_K1H_FUSED=0)\n", self->h_k1h_err[0] - 1);
+		fprintf(stderr, "[fosphor_amd] fused 65536-point FFT: a cluster wait timed out (code 0x%x); "
+		        "results are invalid (set FOSPHOR_AMD_K1H_FUSED=0)\n", self->h_k1h_err[0]);
+		self->h_k1h_err[0] = 0;
 		return -EIO;
 	}
 	self->state = ST_READY;

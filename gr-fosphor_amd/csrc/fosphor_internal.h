@@ -44,7 +44,7 @@ struct K1Params {
 	float2       *scratch;		/* variant 4: [total][N] intermediate spectrum between the two stages */
 	int   iq_half;			/* variant 4: the IQ stream is fp16 (re, im) pairs, 4 B per sample */
 	uint32_t *sync;			/* variant 4, fused form: cluster counters [64][64]; nullptr = two kernels */
-	uint32_t *sync_err;		/* ... its error word (host-mapped) */
+	uint32_t *sync_err;		/* ... its error word (host-mapped): set when a bounded cluster wait times out */
 	int   dbg_k1h;			/* measurement only (FOSPHOR_AMD_DBG_K1H): 1 no cluster waits, 2 no IQ loads, 4 no row / bin stores,
 					 * 8 no intermediate stores / loads -- results are wrong with any of them */
 	int   total;			/* spectra in this launch */

@@ -2049,6 +2049,9 @@ __global__ __launch_bounds__(1024, 4)
 void k1h_fused(const K1Params p)
 {
 	constexpr int N = 65536, QA = 16, M = 512, ROW = M + 1, KB = 64;
+	/* Every wait on another work-group is bounded (a poll is ~1 us: seconds, far beyond any legitimate wait): a protocol failure
+	 * ends the kernel with an error word the host turns into -EIO, it does not hang the GPU. */
+	constexpr uint32_t kSpinLimit = 4u << 20;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	v2f *l4 = reinterpret_cast<v2f *>(smem_raw);			/* stage B, after pass 4: [(i3, jj4)][k]; after pass 5 */
 	v2f *l5 = l4;
@@ -2083,8 +2086,10 @@ void k1h_fused(const K1Params p)
 				__hip_atomic_compare_exchange_strong(state, &st, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			} else {
+				uint32_t spins = 0;
 				while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-					if ((int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntiles) {
+					if ((int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntiles ||
+					    ++spins > kSpinLimit) {			/* (a cluster that never fills is abandoned, never waited for) */
 						uint32_t expect = 0;
 						__hip_atomic_compare_exchange_strong(state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
@@ -2166,8 +2171,11 @@ void k1h_fused(const K1Params p)
 			if (v > 0xfffffu) v = 0xfffffu;
 			__hip_atomic_store(c_t, ((round + 1) << 20) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		} else {
-			while (((v = __hip_atomic_load(c_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != round + 1)
+			uint32_t spins = 0;
+			while (((v = __hip_atomic_load(c_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != round + 1) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000001u; v = 0xfffffu; break; }	/* fail the call, not the GPU */
 				__builtin_amdgcn_s_sleep(2);
+			}
 			v &= 0xfffffu;
 		}
 		sh_tile = (int)v;
@@ -2233,8 +2241,11 @@ void k1h_fused(const K1Params p)
 		}
 		/* every member has read the previous spectrum out of the intermediate? */
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
-			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0)
+			uint32_t spins = 0;
+			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
 				__builtin_amdgcn_s_sleep(1);
+			}
 		}
 		__syncthreads();
 		if (!(p.dbg_k1h & 8)) {
@@ -2255,8 +2266,11 @@ void k1h_fused(const K1Params p)
 			fetch_iq(t + 1);
 
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
-			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0)
+			uint32_t spins = 0;
+			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000003u; break; }
 				__builtin_amdgcn_s_sleep(1);
+			}
 		}
 		__syncthreads();
 		asm volatile("" ::: "memory");
