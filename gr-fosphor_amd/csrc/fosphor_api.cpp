@@ -1359,6 +1359,19 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 		if (sub_c < 1) sub_c = 1;
 		if (chunked && cpb > sub_c) {
 			const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
+			/* K2 counts G consecutive 1024-spectrum chunks per work-group (16-bit counters hold 65535 spectra): 1 / G of the
+			 * slab traffic, as long as enough work-groups are left to keep the bin-index reads in flight */
+			int G = 1;
+			{
+				/* measured, N = 1024, 256 batches per frame: G = 1 / 2 / 4 / 8 -> 486 / 510 / 528 / 450 GSamples/s (at 8 the
+				 * count kernel's 128 work-groups no longer keep up with the FFT kernel) */
+				const char *e = getenv("FOSPHOR_AMD_FRAME_GROUP");
+				for (int want = e ? atoi(e) : 4; want >= 1; want >>= 1)
+					if (want <= 32 && !(want & (want - 1)) && sub_c % want == 0 && cpb % want == 0) {
+						G = want;
+						break;
+					}
+			}
 			const int use_alt = self->overlap && self->alt && !(self->log2n == 16 && self->k1h_fused);
 			int used_alt = 0;
 			if (drain_h_sets(self, st2))
@@ -1406,16 +1419,16 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				memset(&k2, 0, sizeof(k2));
 				k2.bins = self->d_bins; k2.partial = self->d_partial;
 				k2.hc = self->d_hc + (size_t)self->slot * cells;
-				k2.hc16 = self->d_slab16 + (size_t)c0 * cells;
+				k2.hc16 = self->d_slab16 + (size_t)(c0 / G) * cells;
 				k2.n = self->n; k2.bins16 = self->bins16;
-				k2.batch = sub_total; k2.chunk = 1024; k2.tile = tile; k2.n_bins = self->n_bins;
+				k2.batch = sub_total; k2.chunk = 1024 * G; k2.tile = tile; k2.n_bins = self->n_bins;
 				k2.w = 1.0f - self->alpha;
 				k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 				k2.t_offset = t_offset + t0; k2.weight_batch = total_batch;
-				k2.chunk_sum = self->d_chunk_sum + (size_t)c0 * self->n;
-				k2.chunk_max = self->d_chunk_max + (size_t)c0 * self->n;
+				k2.chunk_sum = self->d_chunk_sum + (size_t)(c0 / G) * self->n;
+				k2.chunk_max = self->d_chunk_max + (size_t)(c0 / G) * self->n;
 				prof_begin(self, 1, st2);
-				HIP_TRY(launch_k2(k2, nc, st2), "launch count");
+				HIP_TRY(launch_k2(k2, nc / G, st2), "launch count");
 				prof_end(self, st2);
 				if (self->overlap) {
 					HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
@@ -1428,7 +1441,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
 				k2b.live_sum = self->d_live_sum + (size_t)self->slot * self->n;
 				k2b.vmax = self->d_vmax + (size_t)self->slot * self->n;
-				k2b.n_batches = 1; k2b.cpb = cpb; k2b.n = self->n;
+				k2b.n_batches = 1; k2b.cpb = cpb / G; k2b.n = self->n;
 				k2b.hc16 = self->d_slab16;
 				k2b.hc = self->d_hc + (size_t)self->slot * cells;
 				k2b.n_bins = self->n_bins;

@@ -592,6 +592,30 @@ def test_sharded_frame_many_chunks(amd, torch_cuda, oracle_built, monkeypatch, n
         fr.close()
 
 
+@pytest.mark.parametrize("group", ["1", "2", "4"])
+def test_sharded_frame_grouped_chunks(amd, torch_cuda, oracle_built, monkeypatch, group):
+    """The sub-launched frame path (a shard longer than one sub-launch): the count kernel takes `group` consecutive
+    1024-spectrum chunks per work-group (FOSPHOR_AMD_FRAME_GROUP; default 4 where it divides) -- fewer 16-bit slabs
+    through memory, same counts.  One rank holding the whole 8192-spectrum frame, sub-launches of 4 chunks."""
+    torch = torch_cuda
+    monkeypatch.setenv("FOSPHOR_AMD_SUB_LOG2", "22")
+    monkeypatch.setenv("FOSPHOR_AMD_FRAME_GROUP", group)
+    total = 8192
+    x = add_tone(gaussian_iq(total * 1024, 57), 0.03, 0.21)
+    f = amd.Fosphor(max_spectra=total, n_bins=256)
+    o = Oracle(n_bins=256)
+    for call in range(2):
+        assert f.accumulate_device(torch.from_numpy(x).cuda(), total, 0, total) == 0
+        assert f.merge(total) == 0
+        assert o.process(x, strict=False, nthreads=8) == 0
+        assert np.array_equal(f.hitcount, o.hitcount.T), "call %d" % call
+        assert_hist_close(f.histogram, o.histogram, "grouped frame histogram")
+        assert_close(f.spectrum[0, :, 1], o.spectrum[0, :, 1], "grouped frame live")
+        assert_close(f.spectrum[1, :, 1], o.spectrum[1, :, 1], "grouped frame max-hold")
+    assert_close(f.waterfall, o.waterfall, "grouped frame waterfall")
+    f.close()
+
+
 def overlap_cc_reference(x, wlen, overlap):
     """numpy restatement of lib/overlap_cc_impl.cc:64-79: windows of wlen samples whose starts
     advance wlen/overlap input samples, concatenated."""
