@@ -115,6 +115,8 @@ struct fosphor
 	const uint16_t *export_src;		/* ... made from the last batch's slabs when fosphor_amd_get_buffers asks */
 	const uint32_t *export_mask;
 	uint32_t *d_rowmask;			/* K2 -> K3: one bit per (batch, slab, bin row) "this row has counts and is stored"; 2 sets */
+	unsigned long long *d_wavebits;		/* the same for the N = 1024 dense form: [2 sets][N/64][4 waves][max_batches] */
+	const unsigned long long *export_wavebits;
 	int       mask_words;			/* ceil(n_bins / 32) */
 	uint8_t  *d_hot;			/* [N/64][n_bins]: some cell of the row is above the fast-exit level (K3 maintains it) */
 	uint32_t *d_rowlist;			/* [1 + rows]: the live rows of a merge (sparse form) */
@@ -272,7 +274,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
 	if (self->ev_k1h_gate) (void)hipEventDestroy(self->ev_k1h_gate);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
-	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist);
+	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist); (void)hipFree(self->d_wavebits);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -457,6 +459,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
 	self->mask_words = (self->n_bins + 31) / 32;
 	HIP_TRY(hipMalloc((void **)&self->d_rowmask, sizeof(uint32_t) * 2 * (size_t)self->max_batches * (self->n / 64) * self->mask_words), "alloc row masks");
+	HIP_TRY(hipMalloc((void **)&self->d_wavebits, sizeof(unsigned long long) * 2 * (size_t)self->max_batches * (self->n / 64) * 4), "alloc wave row bits");
 	HIP_TRY(hipMalloc((void **)&self->d_hot, (size_t)(self->n / 64) * self->n_bins), "alloc row flags");
 	HIP_TRY(hipMemset(self->d_hot, 1, (size_t)(self->n / 64) * self->n_bins), "set row flags");
 	HIP_TRY(hipMalloc((void **)&self->d_rowlist, sizeof(uint32_t) * (1 + (size_t)(self->n / 64) * self->n_bins)), "alloc row list");
@@ -738,6 +741,13 @@ static int use_rowmask(const struct fosphor *self)
 	return e ? (*e != '0') : self->log2n == 16;
 }
 
+/* lean sparse hand-off of the N = 1024 dense form (K2 stores / K3 reads only the bin rows with counts; FOSPHOR_AMD_WAVEBITS) */
+static int use_wavebits(const struct fosphor *self)
+{
+	const char *e = getenv("FOSPHOR_AMD_WAVEBITS");
+	return self->log2n == 10 && !self->bins16 && self->n_bins <= 256 && !(self->n_bins & 7) && (e ? (*e != '0') : 0);
+}
+
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
@@ -767,8 +777,12 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 		k2.mask_words = self->mask_words;
 		k2.mask_stride = self->max_batches;
 	}
+	if (k2.hc16 && !k2.rowmask && batch <= 1024 && use_wavebits(self)) {
+		k2.wavebits = self->d_wavebits + (size_t)hset * self->max_batches * (self->n / 64) * 4;
+		k2.mask_stride = self->max_batches;
+	}
 	if (sum16)
-		k2.hc16 = self->d_slab16, k2.rowmask = NULL;
+		k2.hc16 = self->d_slab16, k2.rowmask = NULL, k2.wavebits = NULL;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
@@ -863,6 +877,12 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 			self->hot_valid = 1;
 		} else {
 			self->hot_valid = 0;
+		}
+		self->export_wavebits = NULL;
+		if (!k3.rowmask && batch <= 1024 && use_wavebits(self)) {
+			k3.wavebits = self->d_wavebits + (size_t)hset * self->max_batches * (self->n / 64) * 4;
+			k3.mask_stride = self->max_batches;
+			self->export_wavebits = k3.wavebits + (n_batches - 1);
 		}
 	} else {
 		self->export_src = NULL;
@@ -1243,7 +1263,8 @@ extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_
 		return -EINVAL;
 	if (self->last_hc16 && self->export_src) {
 		/* behind the K2 that wrote the slabs; the view is complete when this call returns */
-		if (launch_export_hc16(self->export_src, self->export_mask, self->mask_words, self->max_batches, self->d_hc_export, self->n_bins, self->n, self->stream2) != hipSuccess ||
+		if (launch_export_hc16(self->export_src, self->export_mask, self->mask_words, self->max_batches, self->d_hc_export, self->n_bins, self->n, self->stream2,
+		                       self->export_wavebits) != hipSuccess ||
 		    hipStreamSynchronize(self->stream2) != hipSuccess)
 			return -EIO;
 		self->export_src = NULL;

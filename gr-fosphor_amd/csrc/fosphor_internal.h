@@ -91,6 +91,9 @@ struct K2Params {
 					 * counts are all zero are NOT stored and their bit is clear (nullptr: every row is stored) */
 	int   mask_words;		/* ceil(n_bins / 32) */
 	int   mask_stride;
+	unsigned long long *wavebits;	/* 8-bit-index geometry (4 waves, n_bins <= 256), alternative to rowmask: [N/64][4][mask_stride] -- wave w's
+					 * 64 bits, bit 2 k + j <-> bin row 8 k + 2 w + j of the slab has counts and is stored.  The bits fall out of
+					 * the store loop's own ballots (SALU), no LDS pass */
 };
 
 struct K2bParams {
@@ -120,6 +123,7 @@ struct K3Params {
 	int   dbg_same;			/* measurement only: every batch reads batch 0's counts */
 	int   cell_begin, cell_end;	/* cells [begin, end) of the (bin, x) array are updated (0, 0 = all): the
 					 * frequency-sliced merge of the multi-GPU split; the columns always are */
+	const unsigned long long *wavebits;	/* dense form at N = 1024: K2's per-wave row bits (see K2Params); rows without counts are not read */
 	const uint32_t *rowmask;	/* hc16 path: K2's row bits (see K2Params) */
 	int   mask_words, mask_stride;
 	uint8_t *hot;			/* hc16 path: [N/64][n_bins] "some cell of this 64-cell row is above the fast-exit level
@@ -153,7 +157,8 @@ hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
-hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s);
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s,
+                              const unsigned long long *wavebits = nullptr);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
 

@@ -2704,6 +2704,24 @@ void k2_count(const K2Params p)
 		/* the LDS image as it is: [bin][32] packed pairs, one contiguous block per work-group
 		 * (32 KiB at 256 bins); K3 unpacks */
 		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)c * (p.n / 64) + blockIdx.x) * nb * 32;
+		if (NW == 4 && p.wavebits) {
+			/* lean sparse hand-off (N = 1024): a wave's step covers two bin rows (2 wv + 8 k and the next); the ballot
+			 * of "dword != 0" says which of the two has counts -- only those are stored, and the 2 x 32 answers are the
+			 * wave's 64 row bits for K3 */
+			unsigned long long bits = 0;
+			int kk = 0;
+			for (int i = tid; i < nb * 32; i += 64 * NW, kk++) {
+				const uint32_t v = h[i];
+				const unsigned long long bal = __ballot(v != 0);
+				const uint32_t b0 = (uint32_t)bal != 0, b1 = (uint32_t)(bal >> 32) != 0;
+				bits |= (unsigned long long)(b0 | (b1 << 1)) << (2 * kk);
+				if ((lane & 32) ? b1 : b0)
+					d[i] = v;
+			}
+			if (lane == 0)
+				p.wavebits[((size_t)blockIdx.x * NW + wv) * p.mask_stride + c] = bits;
+			return;
+		}
 		if (p.rowmask) {
 			/* sparse hand-off: only the bin rows with a count are stored (a wave covers two rows of 32 dwords per
 			 * step), one bit per row tells K3 which; with noise-like input 4 rows in 5 are empty */
@@ -3002,14 +3020,23 @@ void k3_merge(const K3Params p)
 			const int hidx = bin * p.n + slab * 64 + col;
 			const float hv0 = p.hist[hidx];
 			float hv = hv0;
-			{
-				const int fe = p.n_batches;
-				int f = 0;
+			for (int f0 = 0; f0 < p.n_batches; f0 += 64) {
+				/* K2's row bits of this (slab, bin) row for 64 batches: lane l asks for batch f0 + l (one 512-byte request) */
+				unsigned long long m = ~0ull;
+				if (p.wavebits) {
+					const int fl = f0 + (threadIdx.x & 63);
+					const unsigned long long wb = (fl < p.n_batches)
+					        ? p.wavebits[((size_t)slab * 4 + ((bin >> 1) & 3)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0ull;
+					m = __ballot((wb >> (2 * (bin >> 3) + (bin & 1))) & 1ull);
+				}
+				const int fe = (p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
+				int f = f0;
 				for (; f + 8 <= fe; f += 8) {
 					uint32_t hc[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++)
-						hc[u] = __builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
+						hc[u] = ((m >> (f + u - f0)) & 1ull)
+						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]) : 0u;
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
@@ -3021,7 +3048,7 @@ void k3_merge(const K3Params p)
 					}
 				}
 				for (; f < fe; f++) {
-					const uint32_t hc = p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid];
+					const uint32_t hc = ((m >> (f - f0)) & 1ull) ? (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid] : 0u;
 					if (!((hv <= 0.01f) && (hc == 0))) {
 						const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
 						hv = (hv - de.x) * de.y + de.x;
@@ -3436,7 +3463,7 @@ __global__ void k_fill(float *dst, float value, size_t n)
  * store -- clear bit in its row mask -- are zero) */
 __global__ __launch_bounds__(256)
 void k_export_hc16(const uint16_t *__restrict__ hc16, const uint32_t *__restrict__ rowmask, int mask_words, int mask_stride,
-                   uint32_t *__restrict__ out, int n_bins, int n)
+                   uint32_t *__restrict__ out, int n_bins, int n, const unsigned long long *__restrict__ wavebits)
 {
 	const size_t cells = (size_t)n_bins * n;
 	for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < cells; gid += (size_t)gridDim.x * 256) {
@@ -3444,16 +3471,19 @@ void k_export_hc16(const uint16_t *__restrict__ hc16, const uint32_t *__restrict
 		const int rem = (int)(gid - (size_t)slab * n_bins * 64);
 		const int bin = rem >> 6;
 		const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
-		const bool stored = !rowmask || ((rowmask[((size_t)slab * mask_words + (bin >> 5)) * mask_stride] >> (bin & 31)) & 1u);
+		bool stored = !rowmask || ((rowmask[((size_t)slab * mask_words + (bin >> 5)) * mask_stride] >> (bin & 31)) & 1u);
+		if (wavebits)
+			stored = (wavebits[((size_t)slab * 4 + ((bin >> 1) & 3)) * mask_stride] >> (2 * (bin >> 3) + (bin & 1))) & 1ull;
 		out[(size_t)bin * n + slab * 64 + col] = stored ? hc16[gid] : 0u;
 	}
 }
 
-hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s)
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s,
+                              const unsigned long long *wavebits)
 {
 	size_t blocks = ((size_t)n_bins * n + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, rowmask, mask_words, mask_stride, out, n_bins, n);
+	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, rowmask, mask_words, mask_stride, out, n_bins, n, wavebits);
 	return hipGetLastError();
 }
 

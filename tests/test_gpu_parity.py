@@ -273,7 +273,8 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
                                  {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K1": "7"}, {"FOSPHOR_AMD_K23": "1"},
                                  {"FOSPHOR_AMD_ALT": "0"}, {"FOSPHOR_AMD_TILE": "16"}, {"FOSPHOR_AMD_SUB_LOG2": "17"},
                                  {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"},
-                                 {"FOSPHOR_AMD_ROWMASK": "1"}, {"FOSPHOR_AMD_ROWMASK": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"}])
+                                 {"FOSPHOR_AMD_ROWMASK": "1"}, {"FOSPHOR_AMD_ROWMASK": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"},
+                                 {"FOSPHOR_AMD_WAVEBITS": "1"}, {"FOSPHOR_AMD_WAVEBITS": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"}])
 def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
     """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the K1 variants
     (two waves per spectrum; asm-prefetched, one or two spectra ahead; three waves per SIMD with the IQ landing in the
