@@ -2088,8 +2088,10 @@ void k1h_fused(const K1Params p)
 			} else {
 				uint32_t spins = 0;
 				while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-					if ((int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ntiles ||
-					    ++spins > kSpinLimit) {			/* (a cluster that never fills is abandoned, never waited for) */
+					const bool tiles_left = (int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntiles;
+					if (!tiles_left || ++spins > kSpinLimit) {	/* (a cluster that never fills is abandoned, never waited for) */
+						if (tiles_left)
+							*p.sync_err = 0x80000004u;	/* ... but with work left that is a failed call, not a quiet exit */
 						uint32_t expect = 0;
 						__hip_atomic_compare_exchange_strong(state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
