@@ -168,21 +168,18 @@ def main():
         if not args.strict_ordering:
             f.set_input_ordering(False)		# the ring is written once, before the first call
     else:
-        try:
-            sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw)
-            ok = 1
-        except Exception as e:			# the library's own RCCL communicator could not be set up on this rank
-            sys.stderr.write("rank %d: native exchange unavailable (%s)\n" % (rank, e))
-            sf, ok = None, 0
-        if world > 1:
-            # every rank must use the same transport: fall back together to torch.distributed's all-reduces
-            t_ok = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        from gr_fosphor_amd.dist import agree_on_transport
+
+        def all_reduce_min(v):
+            t_ok = torch.tensor([v], dtype=torch.int32, device="cuda")
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-            ok = int(t_ok.item())
-        if not ok:
-            if sf is not None:
-                sf.close()
-            sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", **kw)
+            return int(t_ok.item())
+
+        # the library's own RCCL communicator, or -- on every rank together -- torch.distributed's all-reduces
+        sf, _ = agree_on_transport(lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw),
+                                   lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", **kw),
+                                   world, all_reduce_min,
+                                   log=lambda m: sys.stderr.write("rank %d: %s\n" % (rank, m)))
         f = sf.f
         if not args.strict_ordering:
             f.set_input_ordering(False)
@@ -260,6 +257,20 @@ def main():
                 iso = ms_i[0] / n_i[0]
     f.profile(False)
 
+    # The headline runs with relaxed input ordering (the caller promises to leave the samples alone until finish()); the same
+    # steps with the default, strict ordering against the caller's stream are timed beside it, outside the timed region.
+    strict_value = None
+    if mode == "batch" and not args.strict_ordering and not args.no_extra_passes:
+        f.set_input_ordering(True)
+        run_steps(3)
+        sync()
+        n_strict = max(4, min(args.steps, 40))
+        ts = time.perf_counter()
+        run_steps(n_strict)
+        sync()
+        strict_value = n_strict * F * samples_per_batch / (time.perf_counter() - ts) / 1e6
+        f.set_input_ordering(False)
+
     # the practical ceiling for K1 on this chip: its memory traffic (same loads, order, prefetch depth, stores)
     # without its arithmetic, measured live on the same buffers
     if mode == "batch" and args.config == "C2" and not args.no_traffic_twin:
@@ -292,18 +303,24 @@ def main():
                         "note": "K1 with nothing running beside it (single stream), outside the timed region"}
         # HBM bytes per K1 launch from the PMC passes of the same command (tools/profile_round.sh writes the file):
         # only quoted when it was measured for this very launch shape
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_k1_pmc.json")
-        if os.path.exists(pmc):
+        traffic, traffic_src = None, None
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_k1_pmc*.json")), reverse=True):	# newest round first
             try:
                 j = json.load(open(pmc))
-                if (j.get("config") == args.config and j.get("bins") == bins and
-                        abs(j.get("samples_per_launch", 0) - samples_per_launch) < 1):
-                    traffic = j.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                continue
+            for e in (j if isinstance(j, list) else [j]):
+                if (e.get("config") == args.config and e.get("bins") == bins and
+                        abs(e.get("samples_per_launch", 0) - samples_per_launch) < 1):
+                    traffic, traffic_src = e.get("hbm_bytes_per_launch"), os.path.basename(pmc)
+                    break
+            if traffic:
+                break
+        fused16 = os.environ.get("FOSPHOR_AMD_K1H_FUSED", "1")[:1] != "0"
         k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)", 13: "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
-                   16: "k1h_stage_a + k1h_stage_b (K1, two LDS stages)"}[cfg["log2n"]]
+                   16: "k1h_fused (K1, both LDS stages in one kernel, intermediate in the XCD's L2)" if fused16 else
+                       "k1h_stage_a + k1h_stage_b (K1, two LDS stages, two kernels)"}[cfg["log2n"]]
         if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
             k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"
         sub_b = samples_per_launch / samples_per_batch
@@ -327,6 +344,7 @@ def main():
                              "so a step stores the rows of its last %d of %d spectra (the ring ends in the same state; "
                              "the reference would store all of them)" % (min(wf_rows, F * spb), F * spb),
                 "input_ordering": "strict" if args.strict_ordering else "relaxed",
+                "strict_ordering_value": strict_value,	# MSamples/s of the same steps with the default (strict) ordering, untimed extra pass
                 "host_submit_fraction": t_submit / elapsed,
                 "exchange": "none" if (sf is None or not sf.active) else
                             ("native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
@@ -336,7 +354,7 @@ def main():
                             "torch.distributed all-reduces (RCCL) of hit counts / live sum / max once per frame of %d batches per GPU" % F,
             },
             "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "k1_busy_ms_per_launch": k1_busy, "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
                          "k1_overlap": (ms[0] / busy[0]) if busy[0] > 0 else None,
                          "achieved_plain_average": achieved_plain, "frac_plain_average": achieved_plain / HBM_PEAK_GBS,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "fosphor_amd_process_device_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_finish": (C.c_int, [C.c_void_p]),
     "fosphor_amd_get_buffers": (C.c_int, [C.c_void_p, C.POINTER(Buffers)]),
+    "fosphor_amd_get_buffers_nohc": (C.c_int, [C.c_void_p, C.POINTER(Buffers)]),
     "fosphor_amd_read": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
     "fosphor_amd_fft": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "fosphor_amd_bin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

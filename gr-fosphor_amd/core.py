@@ -117,9 +117,12 @@ class Fosphor:
     def gather_state(self, comm, world, rank):
         return self.L.fosphor_amd_gather_state(self.h, comm, world, rank)
 
-    def buffers(self):
+    def buffers(self, hitcount=True):
+        """struct fosphor_amd_buffers; hitcount=False: no export kernel, no wait, d_hitcount is NULL."""
         b = _lib.Buffers()
-        self.L.fosphor_amd_get_buffers(self.h, C.byref(b))
+        rv = (self.L.fosphor_amd_get_buffers if hitcount else self.L.fosphor_amd_get_buffers_nohc)(self.h, C.byref(b))
+        if rv:
+            raise RuntimeError("fosphor_amd_get_buffers -> %d" % rv)
         return b
 
     # ---- results as host arrays ------------------------------------------
@@ -149,7 +152,7 @@ class Fosphor:
 
     @property
     def waterfall_pos(self):
-        return self.buffers().waterfall_pos
+        return self.buffers(False).waterfall_pos
 
     def colorize(self, image, palette=None, scale=None, offset=None, rows=None):
         """RGBA8 picture of the waterfall (image=0, newest row first) or the histogram (image=1,
@@ -172,11 +175,11 @@ class Fosphor:
 
     @property
     def histo_scale(self):
-        return self.buffers().histo_scale
+        return self.buffers(False).histo_scale
 
     @property
     def histo_offset(self):
-        return self.buffers().histo_offset
+        return self.buffers(False).histo_offset
 
     # ---- kernel-level hooks -------------------------------------------------
     def fft_device(self, d_in, d_out, n_spectra):

@@ -89,7 +89,6 @@ struct fosphor
 	int       n_k1_streams;			/* FOSPHOR_AMD_K1_STREAMS (default 2) */
 	hipEvent_t ev_k1s_done[kMaxK1Streams];
 	int       alt;				/* FOSPHOR_AMD_ALT=0 keeps every K1 on `stream` */
-	int       k23;				/* FOSPHOR_AMD_K23=1: counts and state update fused (k23_strip) */
 	int       k1_seq;
 	int       relaxed;			/* fosphor_amd_set_input_ordering(self, 0) */
 	hipEvent_t ev_in;
@@ -105,18 +104,18 @@ struct fosphor
 	hipEvent_t ev_k1h_gate;			/* N = 65536, fused FFT kernel: the previous piece's merge kernel has finished */
 	int       k1h_gate_set;
 	hipStream_t last_k3_stream;
+	hipStream_t k2_stream_last;		/* stream of the most recent count kernel */
 	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
 	hipEvent_t ev_set_free[kSets];		/* K2 finished reading set pp */
 	int       set_used[kSets];
 	int       overlap;			/* 1: two-stream pipeline for process paths */
-	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum */
+	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum (what odd hops use) */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
 	const uint16_t *export_src;		/* ... made from the last batch's slabs when fosphor_amd_get_buffers asks */
 	const uint32_t *export_mask;
+	hipStream_t export_stream;		/* the stream the K2 that wrote export_src ran on */
 	uint32_t *d_rowmask;			/* K2 -> K3: one bit per (batch, slab, bin row) "this row has counts and is stored"; 2 sets */
-	unsigned long long *d_wavebits;		/* the same for the N = 1024 dense form: [2 sets][N/64][4 waves][max_batches] */
-	const unsigned long long *export_wavebits;
 	int       mask_words;			/* ceil(n_bins / 32) */
 	uint8_t  *d_hot;			/* [N/64][n_bins]: some cell of the row is above the fast-exit level (K3 maintains it) */
 	uint32_t *d_rowlist;			/* [1 + rows]: the live rows of a merge (sparse form) */
@@ -242,6 +241,28 @@ static unsigned dep_event_flags(void)
 	return (e && *e == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
+/* The instance's own streams.  FOSPHOR_AMD_CU_SPLIT=n (experiment): the count / merge streams (kind 1) are
+ * confined to the last n bits of the 256-bit CU mask and the FFT streams (kind 0) to the others, so that K2 / K3 do not take
+ * LDS-pipe and issue slots on the CUs K1 runs on.  0 / unset: no masks (every kernel may use every CU). */
+static hipError_t create_stream(hipStream_t *st, int kind)
+{
+	static const int split = [] { const char *e = getenv("FOSPHOR_AMD_CU_SPLIT"); const int v = e ? atoi(e) : 0;
+	                              return (v > 0 && v < 256) ? v : 0; }();
+	if (!split)
+		return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+	uint32_t mask[8];
+	for (int w = 0; w < 8; w++) {
+		mask[w] = 0;
+		for (int b = 0; b < 32; b++) {
+			const int bit = w * 32 + b;
+			const int in_k23 = bit >= 256 - split;
+			if ((kind == 1) == (in_k23 != 0))
+				mask[w] |= 1u << b;
+		}
+	}
+	return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
 extern "C" const char *fosphor_amd_version(void) { return FOSPHOR_AMD_VERSION; }
 
 extern "C" void fosphor_release(struct fosphor *self)
@@ -274,7 +295,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
 	if (self->ev_k1h_gate) (void)hipEventDestroy(self->ev_k1h_gate);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
-	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist); (void)hipFree(self->d_wavebits);
+	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
 	(void)hipFree(self->d_chunk_sum); (void)hipFree(self->d_chunk_max);
 	(void)hipFree(self->d_rise);
@@ -365,7 +386,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	if (cfg && cfg->stream) {
 		self->stream = (hipStream_t)cfg->stream;
 	} else {
-		HIP_TRY(hipStreamCreateWithFlags(&self->stream, hipStreamNonBlocking), "hipStreamCreate");
+		HIP_TRY(create_stream(&self->stream, 0), "hipStreamCreate");
 		self->own_stream = 1;
 	}
 
@@ -387,7 +408,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	self->k1_streams[0] = self->stream;
 	for (int i = 1; i < self->n_k1_streams; i++) {
-		HIP_TRY(hipStreamCreateWithFlags(&self->k1_streams[i], hipStreamNonBlocking), "hipStreamCreate (FFT stream)");
+		HIP_TRY(create_stream(&self->k1_streams[i], 0), "hipStreamCreate (FFT stream)");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1s_done[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
@@ -416,8 +437,8 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	/* host staging slot: the reference's cap of 1024 spectra per call (cl.c:885), or this instance's */
 	self->stage_samples = (size_t)self->n * (self->max_spectra < 1024 ? self->max_spectra : 1024);
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	HIP_TRY(create_stream(&self->stream2, 1), "hipStreamCreate (count stream)");
+	HIP_TRY(create_stream(&self->stream3, 1), "hipStreamCreate (merge stream)");
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k2_done[i], dep_event_flags()), "create event");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
@@ -437,7 +458,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		if (self->log2n == 16 && self->k1h_fused && !(e && *e == '1'))
 			self->overlap = 0;
 		e = getenv("FOSPHOR_AMD_K1");
-		self->k1_variant = (e && *e == '2') ? 2 : (e && *e == '5') ? 5 : (e && *e == '6') ? 6 : (e && *e == '7') ? 7 : 1;
+		self->k1_variant = (e && *e == '2') ? 2 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
 		self->pipe3 = (e && *e == '1');
 		e = getenv("FOSPHOR_AMD_ALT");
@@ -446,10 +467,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->n_sets = (e && atoi(e) >= 2 && atoi(e) <= kSets) ? atoi(e) : 3;
 		if (self->n_k1_streams == 1)
 			self->alt = 0;
-		/* fused count + merge (k23_strip): 9 % fewer bytes, but its batches are a serial chain (1.6 us each) that
-		 * today costs more than the bytes it saves -- opt-in until that chain is shorter */
-		e = getenv("FOSPHOR_AMD_K23");
-		self->k23 = (e && *e == '1');
 		e = getenv("FOSPHOR_AMD_SUB_LOG2");		/* tuning: log2 of the samples per sub-launch */
 		/* (N = 8192: the one-work-group-per-CU FFT kernel owns the whole LDS, so K2 cannot run beside it and a
 		 * smaller piece only adds serialised kernel boundaries: twice the default) */
@@ -459,7 +476,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
 	self->mask_words = (self->n_bins + 31) / 32;
 	HIP_TRY(hipMalloc((void **)&self->d_rowmask, sizeof(uint32_t) * 2 * (size_t)self->max_batches * (self->n / 64) * self->mask_words), "alloc row masks");
-	HIP_TRY(hipMalloc((void **)&self->d_wavebits, sizeof(unsigned long long) * 2 * (size_t)self->max_batches * (self->n / 64) * 4), "alloc wave row bits");
 	HIP_TRY(hipMalloc((void **)&self->d_hot, (size_t)(self->n / 64) * self->n_bins), "alloc row flags");
 	HIP_TRY(hipMemset(self->d_hot, 1, (size_t)(self->n / 64) * self->n_bins), "set row flags");
 	HIP_TRY(hipMalloc((void **)&self->d_rowlist, sizeof(uint32_t) * (1 + (size_t)(self->n / 64) * self->n_bins)), "alloc row list");
@@ -562,17 +578,20 @@ static void prof_begin(struct fosphor *self, int kind, hipStream_t st)
 			self->ev_pool.push_back(e);
 		}
 	}
+	if (hipEventRecord(self->ev_pool[self->ev_used], st) != hipSuccess)
+		return;				/* this launch goes untimed */
 	self->prof_open = 1;
 	self->ev_kind.push_back(kind);
-	(void)hipEventRecord(self->ev_pool[self->ev_used], st);
 }
 
 static void prof_end(struct fosphor *self, hipStream_t st)
 {
 	if (!self->prof_open) return;
 	self->prof_open = 0;
-	if (self->ev_used + 2 > self->ev_pool.size()) return;
-	(void)hipEventRecord(self->ev_pool[self->ev_used + 1], st);
+	if (self->ev_used + 2 > self->ev_pool.size() || hipEventRecord(self->ev_pool[self->ev_used + 1], st) != hipSuccess) {
+		self->ev_kind.pop_back();	/* drop the half-recorded pair */
+		return;
+	}
 	self->ev_used += 2;
 }
 
@@ -618,14 +637,19 @@ static int drain_h_sets(struct fosphor *self, hipStream_t st)
 /* Upload lazily-changed tables (cl.c:889-900) and boot fills (cl.c:406-465, 930-934) */
 static int prepare(struct fosphor *self)
 {
+	if (self->win_dirty || self->thr_dirty) {
+		/* The tables are read by every K1 still queued -- with relaxed input ordering those of the previous call may be
+		 * running on the other FFT streams, which `stream` does not wait for -- and the pinned staging copies (h_win,
+		 * h_thr) may still be in flight: drain all FFT streams before either is rewritten. */
+		for (int i = 0; i < self->n_k1_streams; i++)
+			HIP_TRY(hipStreamSynchronize(self->k1_streams[i]), "drain FFT streams before a table upload");
+	}
 	if (self->win_dirty) {
-		(void)hipStreamSynchronize(self->stream);	/* h_win may still be in flight */
 		memcpy(self->h_win, self->fft_win, sizeof(float) * self->n);
 		HIP_TRY(hipMemcpyAsync(self->d_win, self->h_win, sizeof(float) * self->n, hipMemcpyHostToDevice, self->stream), "upload window");
 		self->win_dirty = 0;
 	}
 	if (self->thr_dirty) {
-		(void)hipStreamSynchronize(self->stream);
 		build_thresholds(self->h_thr, self->n_bins, self->histo_scale, self->histo_offset);
 		HIP_TRY(hipMemcpyAsync(self->d_thr, self->h_thr, sizeof(double) * (self->n_bins + 1), hipMemcpyHostToDevice, self->stream), "upload thresholds");
 		self->thr_dirty = 0;
@@ -719,7 +743,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 		k1->dbg_k1h = dbg;
 	}
 	k1->iq_half = self->iq_half;
-	if ((k1->variant == 1 || k1->variant >= 5) && (k1->hop & 1))
+	if (k1->variant == 1 && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
 
@@ -731,21 +755,14 @@ static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
 	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !getenv("FOSPHOR_AMD_NO_BIGCHUNK");
 }
 
-/* Sparse K2 -> K3 hand-off (row masks + hot flags): pays where the state is large and one batch is a whole frame
- * (N = 65536: 128 MiB of state, +10 % for the path); at N = 1024 K3 is bound by its 64-batch dependent chain, not by the
- * rows it touches, and K2's mask costs more than K3 saves (measured -1 %; N = 8192: -2.5 %).
- * FOSPHOR_AMD_ROWMASK=0 / 1 forces it off / on. */
+/* Sparse K2 -> K3 hand-off (row masks + hot flags) for the large state of N = 65536 (128 MiB, one batch = one frame: +10 % for
+ * the path).  At N = 1024 / 8192 it measured slower (K3 there is bound by its dependent chain over the batches of a launch,
+ * not by the rows it touches: -1 % / -2.5 %) and is not offered.  FOSPHOR_AMD_ROWMASK=0 selects the dense form at N = 65536
+ * (the tests run both). */
 static int use_rowmask(const struct fosphor *self)
 {
 	const char *e = getenv("FOSPHOR_AMD_ROWMASK");
-	return e ? (*e != '0') : self->log2n == 16;
-}
-
-/* lean sparse hand-off of the N = 1024 dense form (K2 stores / K3 reads only the bin rows with counts; FOSPHOR_AMD_WAVEBITS) */
-static int use_wavebits(const struct fosphor *self)
-{
-	const char *e = getenv("FOSPHOR_AMD_WAVEBITS");
-	return self->log2n == 10 && !self->bins16 && self->n_bins <= 256 && !(self->n_bins & 7) && (e ? (*e != '0') : 0);
+	return self->log2n == 16 && !(e && *e == '0');
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -777,12 +794,8 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 		k2.mask_words = self->mask_words;
 		k2.mask_stride = self->max_batches;
 	}
-	if (k2.hc16 && !k2.rowmask && batch <= 1024 && use_wavebits(self)) {
-		k2.wavebits = self->d_wavebits + (size_t)hset * self->max_batches * (self->n / 64) * 4;
-		k2.mask_stride = self->max_batches;
-	}
 	if (sum16)
-		k2.hc16 = self->d_slab16, k2.rowmask = NULL, k2.wavebits = NULL;
+		k2.hc16 = self->d_slab16, k2.rowmask = NULL;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
@@ -801,6 +814,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	}
 	prof_begin(self, 1, st);
 	HIP_TRY(launch_k2(k2, n_batches * cpb, st), "launch count");
+	self->k2_stream_last = st;
 	if (cpb > 1) {
 		memset(&k2b, 0, sizeof(k2b));
 		k2b.chunk_sum = self->d_chunk_sum; k2b.chunk_max = self->d_chunk_max;
@@ -828,7 +842,8 @@ static int ensure_rise_table(struct fosphor *self, int batch, hipStream_t st)
 		return 0;
 	if (self->rise_batch == batch && self->rise_t0r == self->t0r && self->rise_t0d == self->t0d)
 		return 1;
-	(void)sync_all(self);				/* h_rise may be in flight */
+	if (sync_all(self))				/* h_rise may be in flight */
+		return -1;
 	for (int hc = 0; hc <= batch; hc++) {
 		const float a = (float)hc / (float)batch;
 		const float b = a * (1.0f / self->t0r);
@@ -866,6 +881,7 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 		k3.hc_export = NULL;
 		self->export_src = k3.hc16 + (size_t)(n_batches - 1) * cells;
 		self->export_mask = NULL;
+		self->export_stream = self->k2_stream_last ? self->k2_stream_last : st;
 		if (use_rowmask(self)) {
 			k3.rowmask = self->d_rowmask + (size_t)hset * self->max_batches * per_batch;
 			k3.mask_words = self->mask_words;
@@ -877,12 +893,6 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 			self->hot_valid = 1;
 		} else {
 			self->hot_valid = 0;
-		}
-		self->export_wavebits = NULL;
-		if (!k3.rowmask && batch <= 1024 && use_wavebits(self)) {
-			k3.wavebits = self->d_wavebits + (size_t)hset * self->max_batches * (self->n / 64) * 4;
-			k3.mask_stride = self->max_batches;
-			self->export_wavebits = k3.wavebits + (n_batches - 1);
 		}
 	} else {
 		self->export_src = NULL;
@@ -897,36 +907,6 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
 	prof_begin(self, 2, st);
 	HIP_TRY(launch_k3(k3, st), "launch merge");
-	prof_end(self, st);
-	return 0;
-error:
-	return -EIO;
-}
-
-/* Counts and state update fused (k23_strip): N = 1024 path with 8-bit bin indices, batch <= 1024. */
-static int k23_ok(const struct fosphor *self, int batch)
-{
-	return self->k23 && self->log2n == 10 && !self->bins16 && batch <= 1024 && batch <= kRiseMax;
-}
-
-static int run_k23(struct fosphor *self, int n_batches, int batch, int tile, hipStream_t st)
-{
-	K23Params k;
-	if (ensure_rise_table(self, batch, st) <= 0 || k3_stream_enter(self, st))
-		return -EIO;
-	memset(&k, 0, sizeof(k));
-	k.bins = self->d_bins; k.partial = self->d_partial;
-	k.hist = self->d_hist; k.spectrum = self->d_spectrum;
-	k.hc_export = self->d_hc_export;
-	self->export_src = NULL;
-	self->hot_valid = 0;
-	k.rise = self->d_rise;
-	k.n = self->n; k.n_bins = self->n_bins; k.n_batches = n_batches; k.batch = batch; k.tile = tile;
-	k.log2_w = (float)log2((double)(1.0f - self->alpha));
-	k.alpha = self->alpha;
-	k.live_decay = powf(1.0f - self->alpha, (float)batch);	/* display.cl:210 */
-	prof_begin(self, 1, st);
-	HIP_TRY(launch_k23(k, st), "launch count+merge");
 	prof_end(self, st);
 	return 0;
 error:
@@ -1073,16 +1053,6 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 			}
 			continue;
 		}
-		if (k23_ok(self, batch)) {
-			if (drain_h_sets(self, st2) || run_k23(self, nb, batch, tile, st2))
-				return -EIO;
-			if (self->overlap) {
-				HIP_TRY(hipEventRecord(self->ev_set_free[set], st2), "record set free");
-				self->set_used[set] = 1;
-			}
-			self->last_batches = nb;
-			continue;
-		}
 		if (three) {
 			hset = self->hset;
 			self->hset ^= 1;
@@ -1186,7 +1156,8 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 		int rv = run(self, self->d_stage[k], 1, len / self->n);
 		/* the slot is free again once everything queued so far (copy + kernels reading
 		 * d_stage[k]) has finished */
-		(void)hipEventRecord(self->stage_free[k], self->stream);
+		if (hipEventRecord(self->stage_free[k], self->stream) != hipSuccess && !rv)
+			rv = -EIO;
 		self->stage_idx ^= 1;
 		return rv;
 	}
@@ -1257,27 +1228,39 @@ extern "C" void fosphor_draw(struct fosphor *self, struct fosphor_render *render
 /* Buffers                                                                  */
 /* ------------------------------------------------------------------------ */
 
-extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out)
+static int get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out, int want_hitcount)
 {
 	if (!self || !out)
 		return -EINVAL;
-	if (self->last_hc16 && self->export_src) {
-		/* behind the K2 that wrote the slabs; the view is complete when this call returns */
-		if (launch_export_hc16(self->export_src, self->export_mask, self->mask_words, self->max_batches, self->d_hc_export, self->n_bins, self->n, self->stream2,
-		                       self->export_wavebits) != hipSuccess ||
-		    hipStreamSynchronize(self->stream2) != hipSuccess)
+	if (want_hitcount && self->last_hc16 && self->export_src) {
+		/* queued on the stream of the K2 that wrote the slabs (stream order = behind it); the view is complete when
+		 * this call returns */
+		hipStream_t st = self->export_stream ? self->export_stream : self->stream;
+		if (launch_export_hc16(self->export_src, self->export_mask, self->mask_words, self->max_batches, self->d_hc_export, self->n_bins, self->n, st) != hipSuccess ||
+		    hipStreamSynchronize(st) != hipSuccess)
 			return -EIO;
 		self->export_src = NULL;
 	}
 	out->d_waterfall = self->d_wf_pp[self->wf_cur];
 	out->d_histogram = self->d_hist;
 	out->d_spectrum  = (float *)self->d_spectrum;
-	out->d_hitcount  = self->last_hc16 ? self->d_hc_export
+	out->d_hitcount  = !want_hitcount ? NULL : self->last_hc16 ? self->d_hc_export
 	                   : self->d_hc + (size_t)(self->last_slot0 + (self->last_batches > 0 ? self->last_batches - 1 : 0)) * self->n_bins * self->n;
 	out->waterfall_pos = self->wf_pos;
 	out->fft_len = self->n; out->n_bins = self->n_bins; out->wf_rows = self->wf_rows;
 	out->histo_scale = self->histo_scale; out->histo_offset = self->histo_offset;
 	return 0;
+}
+
+extern "C" int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out)
+{
+	return get_buffers(self, out, 1);
+}
+
+/* The same without the hit-count view (d_hitcount = NULL): nothing is launched, nothing is waited for. */
+extern "C" int fosphor_amd_get_buffers_nohc(struct fosphor *self, struct fosphor_amd_buffers *out)
+{
+	return get_buffers(self, out, 0);
 }
 
 extern "C" int fosphor_amd_read(struct fosphor *self, int which, void *host, uint64_t bytes)
@@ -1291,7 +1274,9 @@ extern "C" int fosphor_amd_read(struct fosphor *self, int which, void *host, uin
 	rv = fosphor_amd_finish(self);
 	if (rv < 0)
 		return rv;
-	fosphor_amd_get_buffers(self, &b);
+	rv = get_buffers(self, &b, which == 3);
+	if (rv < 0)
+		return rv;
 	switch (which) {
 	case 0: src = b.d_waterfall; want = sizeof(float) * (uint64_t)self->wf_rows * self->n; break;
 	case 1: src = b.d_histogram; want = sizeof(float) * (uint64_t)self->n_bins * self->n; break;
@@ -1316,7 +1301,8 @@ extern "C" int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_o
 	int saved_state;
 	if (!self || !d_in || !d_out || n_spectra < 4 || (n_spectra & 3) || n_spectra > self->max_spectra)
 		return -EINVAL;
-	(void)sync_all(self);				/* scratch sets may still be read by a queued K2 */
+	if (sync_all(self))				/* scratch sets may still be read by a queued K2 */
+		return -EIO;
 	saved_state = self->state;
 	self->state = ST_READY;			/* no boot fills for a pure FFT */
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -1337,7 +1323,8 @@ extern "C" int fosphor_amd_bin(struct fosphor *self, const void *d_fft, void *d_
 	if (!self || !d_fft || !d_bin || !d_pwr || n < 1)
 		return -EINVAL;
 	if (e && *e == '1') force = 1;
-	(void)sync_all(self);
+	if (sync_all(self))
+		return -EIO;
 	saved_state = self->state;
 	self->state = ST_READY;
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
@@ -1652,6 +1639,7 @@ extern "C" int fosphor_amd_gather_state(struct fosphor *self, void *comm, int wo
 	hipStream_t st = self->overlap ? self->stream2 : self->stream;
 	if (k3_stream_enter(self, st))
 		return -EIO;
+	self->hot_valid = 0;		/* other ranks' cells arrive: the hot-row flags of the sparse merge no longer describe d_hist */
 	return xchg_allgather_f32(comm, st, self->d_hist, cells, world, rank);
 }
 
@@ -1739,12 +1727,19 @@ extern "C" int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samp
 	fill_k1(self, &k1, d_samples, total, pick_tile(self, total, batch), 0, total);
 	if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
 		return -EIO;
-	for (int i = 0; i < 3; i++)
-		(void)launch_k1_traffic_twin(k1, self->stream);
-	(void)hipEventRecord(e0, self->stream);
-	for (int i = 0; i < reps; i++)
-		(void)launch_k1_traffic_twin(k1, self->stream);
-	(void)hipEventRecord(e1, self->stream);
+	{
+		hipError_t le = hipSuccess;
+		for (int i = 0; i < 3 && le == hipSuccess; i++)
+			le = launch_k1_traffic_twin(k1, self->stream);
+		if (le == hipSuccess) le = hipEventRecord(e0, self->stream);
+		for (int i = 0; i < reps && le == hipSuccess; i++)
+			le = launch_k1_traffic_twin(k1, self->stream);
+		if (le == hipSuccess) le = hipEventRecord(e1, self->stream);
+		if (le != hipSuccess) {
+			(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+			return -EIO;
+		}
+	}
 	if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
 		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 		return -EIO;

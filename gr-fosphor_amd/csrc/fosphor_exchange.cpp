@@ -17,23 +17,33 @@
 
 #include <mutex>
 
-#include <rccl/rccl.h>
-
 #include "fosphor_internal.h"
+
+/* The slice of the NCCL / RCCL C ABI this file binds with dlsym, declared here so that the library builds where no
+ * RCCL headers are installed (a single-GPU user needs neither headers nor library).  Values are the public ABI of
+ * nccl.h / rccl.h (stable since NCCL 2.x; checked against /opt/rocm/include/rccl/rccl.h: ncclSuccess 0, ncclSum 0,
+ * ncclMax 2, ncclUint32 3, ncclFloat32 7, 128-byte unique id). */
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+typedef enum { ncclUint32 = 3, ncclFloat32 = 7 } ncclDataType_t;
+}
 
 namespace fosphor_amd {
 
 struct Rccl {
 	void *lib;
-	decltype(&ncclGetUniqueId)   GetUniqueId;
-	decltype(&ncclCommInitRank)  CommInitRank;
-	decltype(&ncclCommDestroy)   CommDestroy;
-	decltype(&ncclGroupStart)    GroupStart;
-	decltype(&ncclGroupEnd)      GroupEnd;
-	decltype(&ncclAllReduce)     AllReduce;
-	decltype(&ncclReduceScatter) ReduceScatter;
-	decltype(&ncclAllGather)     AllGather;
-	decltype(&ncclGetErrorString) GetErrorString;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int nranks, ncclUniqueId id, int rank);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*GroupStart)(void);
+	ncclResult_t (*GroupEnd)(void);
+	ncclResult_t (*AllReduce)(const void *send, void *recv, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+	ncclResult_t (*ReduceScatter)(const void *send, void *recv, size_t recvcount, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+	ncclResult_t (*AllGather)(const void *send, void *recv, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t);
+	const char  *(*GetErrorString)(ncclResult_t);
 };
 
 static Rccl *rccl(void)

@@ -56,7 +56,7 @@ struct K1Params {
 	float amb;			/* confident when |v - rint(v)| + kappa |l2| <= amb */
 	float kappa;			/* v_log_f32 error bound per unit of |log2 s|, through the slope binA */
 	float w;			/* 1 - alpha */
-	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum; 3: general N (N/8 threads per
+	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum (odd hops); 3: general N (N/8 threads per
 					 * spectrum, one LDS slab); 4: N = 65536 in two LDS stages */
 };
 
@@ -91,9 +91,6 @@ struct K2Params {
 					 * counts are all zero are NOT stored and their bit is clear (nullptr: every row is stored) */
 	int   mask_words;		/* ceil(n_bins / 32) */
 	int   mask_stride;
-	unsigned long long *wavebits;	/* 8-bit-index geometry (4 waves, n_bins <= 256), alternative to rowmask: [N/64][4][mask_stride] -- wave w's
-					 * 64 bits, bit 2 k + j <-> bin row 8 k + 2 w + j of the slab has counts and is stored.  The bits fall out of
-					 * the store loop's own ballots (SALU), no LDS pass */
 };
 
 struct K2bParams {
@@ -123,7 +120,6 @@ struct K3Params {
 	int   dbg_same;			/* measurement only: every batch reads batch 0's counts */
 	int   cell_begin, cell_end;	/* cells [begin, end) of the (bin, x) array are updated (0, 0 = all): the
 					 * frequency-sliced merge of the multi-GPU split; the columns always are */
-	const unsigned long long *wavebits;	/* dense form at N = 1024: K2's per-wave row bits (see K2Params); rows without counts are not read */
 	const uint32_t *rowmask;	/* hc16 path: K2's row bits (see K2Params) */
 	int   mask_words, mask_stride;
 	uint8_t *hot;			/* hc16 path: [N/64][n_bins] "some cell of this 64-cell row is above the fast-exit level
@@ -133,32 +129,14 @@ struct K3Params {
 	uint32_t *rowlist;		/* sparse form: [1 + rows] count, then the live rows (k3_scan writes, k3_merge reads) */
 };
 
-/* K23: hit counts AND state update in one kernel (N = 1024 path, 8-bit bin indices, batch <= 1024).
- * One work-group owns 4 columns for the whole launch and walks the batches in order: count the batch's
- * spectra into LDS, then apply rise/decay to its 4 x n_bins cells (state in registers), live EMA and max-hold
- * to its 4 columns.  The per-batch hit counts never leave the CU (K2 -> K3 moved 0.5 B per sample each way). */
-struct K23Params {
-	const uint32_t *bins;		/* [total/4][N] */
-	const float2   *partial;	/* [total/tile][N] */
-	float    *hist;			/* [n_bins][N] */
-	float2   *spectrum;		/* [2][N] */
-	uint32_t *hc_export;		/* [n_bins][N] counts of the launch's last batch */
-	const float2 *rise;		/* [batch+1] (d, e) per hit count */
-	int   n, n_bins, n_batches, batch, tile;
-	float log2_w;			/* log2(1 - alpha) */
-	float alpha, live_decay;	/* display.cl:210-211 */
-};
-
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
-hipError_t launch_k23(const K23Params &p, hipStream_t s);
 hipError_t launch_k1_traffic_twin(const K1Params &p, hipStream_t s);
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s);
 hipError_t launch_k2b(const K2bParams &p, hipStream_t s);
 hipError_t launch_k2c(const K2bParams &p, hipStream_t s);
 hipError_t launch_k3(const K3Params &p, hipStream_t s);
 hipError_t launch_fill(float *dst, float value, size_t n, hipStream_t s);
-hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s,
-                              const unsigned long long *wavebits = nullptr);
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s);
 hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
 

@@ -33,13 +33,10 @@ namespace fosphor_amd {
 /* ------------------------------------------------------------------------ */
 /* A complex value is one 64-bit VGPR pair (re, im).  Every helper performs exactly the IEEE
  * operations of the reference expression it cites -- only the instruction selection differs:
- * with K1_ASM_PK the half-swaps and sign flips of the reference's "multiply by -j" and of the
+ * the half-swaps and sign flips of the reference's "multiply by -j" and of the
  * complex product ride on VOP3P op_sel / neg modifiers instead of costing v_mov / extra adds.
  * x - (-y) and x + y are the same IEEE operation, as are a*b and b*a, a+b and b+a.          */
 
-#ifndef K1_ASM_PK
-#define K1_ASM_PK 1
-#endif
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -48,65 +45,42 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 /* fft.cl:37-46 : (a.x*w.x - a.y*w.y, a.x*w.y + a.y*w.x) */
 static __device__ __forceinline__ v2f c_mul(v2f a, v2f w)
 {
-#if K1_ASM_PK
 	v2f t1, t2, r;
 	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1) : "v"(a), "v"(w));			/* (a.x*w.x, a.y*w.x) */
 	asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t2) : "v"(a), "v"(w));	/* (a.y*w.y, a.x*w.y) */
 	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));			/* (t1.x - t2.x, t1.y + t2.y) */
 	return r;
-#else
-	v2f r;
-	r.x = a.x * w.x - a.y * w.y;
-	r.y = a.x * w.y + a.y * w.x;
-	return r;
-#endif
 }
 
 /* a + mul_p1q2(b) and a - mul_p1q2(b), mul_p1q2(b) = (b.y, -b.x)  (fft.cl:77, used by dft8) */
 static __device__ __forceinline__ v2f add_mj(v2f a, v2f b)
 {
-#if K1_ASM_PK
 	v2f r;
 	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
 	return r;
-#else
-	v2f r; r.x = a.x + b.y; r.y = a.y + (-b.x); return r;
-#endif
 }
 static __device__ __forceinline__ v2f sub_mj(v2f a, v2f b)
 {
-#if K1_ASM_PK
 	v2f r;
 	asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
 	return r;
-#else
-	v2f r; r.x = a.x - b.y; r.y = a.y - (-b.x); return r;
-#endif
 }
 
 /* fft.cl:80 : SQRT_1_2 * (a.x + a.y, -a.x + a.y) */
 static __device__ __forceinline__ v2f mul_p1q4(v2f a, v2f s12)
 {
-#if K1_ASM_PK
 	v2f t, r;
 	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a));	/* (a.x + a.y, a.y + -a.x) */
 	asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(s12));
 	return r;
-#else
-	v2f r; r.x = s12.x * (a.x + a.y); r.y = s12.y * (-a.x + a.y); return r;
-#endif
 }
 /* fft.cl:82 : SQRT_1_2 * (-a.x + a.y, -a.x - a.y) */
 static __device__ __forceinline__ v2f mul_p3q4(v2f a, v2f s12)
 {
-#if K1_ASM_PK
 	v2f t, r;
 	asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(t) : "v"(a));	/* (-a.x + a.y, -a.x + -a.y) */
 	asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(s12));
 	return r;
-#else
-	v2f r; r.x = s12.x * (-a.x + a.y); r.y = s12.y * (-a.x - a.y); return r;
-#endif
 }
 
 /* fft.cl:86-94 */
@@ -127,19 +101,11 @@ static __device__ __forceinline__ void dft8(v2f (&r)[8], v2f s12)
 /* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
 static __device__ __forceinline__ v2f mul_bcast_lo(v2f x, v2f w)
 {
-#if K1_ASM_PK
 	v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(w)); return r;
-#else
-	v2f r; r.x = x.x * w.x; r.y = x.y * w.x; return r;
-#endif
 }
 static __device__ __forceinline__ v2f mul_bcast_hi(v2f x, v2f w)
 {
-#if K1_ASM_PK
 	v2f r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(x), "v"(w)); return r;
-#else
-	v2f r; r.x = x.x * w.y; r.y = x.y * w.y; return r;
-#endif
 }
 
 /* Order in which a radix-8 pass stores its outputs: offsets {0,p,..,7p} receive
@@ -278,27 +244,6 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 #ifndef K1_WAVES_PER_SIMD
 #define K1_WAVES_PER_SIMD 2		/* __launch_bounds__ second argument */
 #endif
-#ifndef K1_PREFETCH
-#define K1_PREFETCH 1			/* register prefetch of the next spectrum */
-#endif
-#ifndef K1_LOAD16
-#define K1_LOAD16 1			/* 1: 16-byte IQ loads, lane L owns pass-1 items 2L and 2L+1; 0: 8-byte loads, items L and L+64 */
-#endif
-#ifndef K1_PRIO
-#define K1_PRIO 0
-#endif
-#ifndef K1_NT_BINS
-#define K1_NT_BINS 0			/* non-temporal stores for the bin indices (measured: see DESIGN.md) */
-#endif
-#ifndef K2_NT_LOAD
-#define K2_NT_LOAD 0			/* non-temporal loads of the bin indices in K2 */
-#endif
-#ifndef K1_UNIFORM
-#define K1_UNIFORM 1			/* wave-uniform control values in SGPRs, in-place Horner, one branch for the row stores */
-#endif
-#ifndef K1_TW3_LDS
-#define K1_TW3_LDS 0			/* pass-3 twiddles from an LDS table instead of registers */
-#endif
 
 /* K1_TIMING=1 (debug builds only, tools/k1_phase_timing.py): s_memtime stamps per phase,
  * accumulated per wave into K1Params::dbg[wave][phase]. */
@@ -314,7 +259,6 @@ static __device__ __forceinline__ float max_f32(float a, float b)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-#if K1_LOAD16
 /* 8 x (64 lanes x 16 B) = 1 KiB per instruction, read-once: non-temporal.  `src` points at this
  * lane's pair: elements (2L, 2L+1) + 128k land in x[2k], x[2k+1].  (Ablation on MI355X: with
  * 8-byte-per-lane loads the load path alone caps K1 near 4.7 TB/s; 16-byte ones do not.) */
@@ -328,16 +272,6 @@ static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__r
 	}
 }
 #define K1_LANE_SRC(lane) (2 * (lane))
-#else
-/* 16 x (64 lanes x 8 B) coalesced, read-once: non-temporal */
-static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__restrict__ src)
-{
-#pragma unroll
-	for (int m = 0; m < 16; m++)
-		x[m] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + 64 * m));
-}
-#define K1_LANE_SRC(lane) (lane)
-#endif
 
 template <bool WRITE_FFT>
 __global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
@@ -346,19 +280,9 @@ void k1_fft_bin(const K1Params p)
 	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
 	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles, shared by the block */
 	__shared__ float win_tab[kN];			/* window, shared by the block */
-#if K1_TW3_LDS
-	__shared__ v2f   tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
-#endif
 
-#if K1_PRIO
-	__builtin_amdgcn_s_setprio(K1_PRIO);		/* K1's waves go first; the count / merge waves beside them take what is left */
-#endif
 	const int lane   = threadIdx.x & 63;
-#if K1_UNIFORM
 	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);	/* tile, spectrum index, row predicate: SGPRs */
-#else
-	const int wv     = threadIdx.x >> 6;
-#endif
 	const int ntiles = p.total / p.tile;
 	const int stride = gridDim.x * 4;		/* waves in the grid */
 #if K1_TIMING
@@ -371,10 +295,6 @@ void k1_fft_bin(const K1Params p)
 		win_tab[i] = p.win[i];
 	for (int i = threadIdx.x; i < 512; i += 256)
 		tw4_tab[i] = twg[kTw4Off + i];
-#if K1_TW3_LDS
-	for (int i = threadIdx.x; i < 7 * 64; i += 256)
-		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
-#endif
 	__syncthreads();				/* the only block-wide barrier */
 
 	if (tile >= ntiles)
@@ -384,15 +304,11 @@ void k1_fft_bin(const K1Params p)
 
 	/* ---- per-lane constants, loaded once per wave -------------------------- */
 	v2f tw2[7];
-#if !K1_TW3_LDS
 	v2f tw3[7];
-#endif
 #pragma unroll
 	for (int n = 0; n < 7; n++) {
 		tw2[n] = twg[kTw2Off + (lane & 7) * 7 + n];	/* k = i & 7  (both virtual items) */
-#if !K1_TW3_LDS
 		tw3[n] = twg[kTw3Off + lane * 7 + n];		/* k = i & 63 = lane               */
-#endif
 	}
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
 
@@ -413,9 +329,7 @@ void k1_fft_bin(const K1Params p)
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;	/* display.cl:91, in log2 units */
 
 	v2f xn[16];
-#if K1_PREFETCH
 	load_iq16(xn, p.iq + (size_t)tile * p.tile * p.hop + K1_LANE_SRC(lane));
-#endif
 #if K1_TIMING
 	long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	long long tprev = __builtin_readcyclecounter();
@@ -444,30 +358,15 @@ void k1_fft_bin(const K1Params p)
 			const int t = t0 + g0 + u;
 			v2f x[16];
 
-#if !K1_PREFETCH
-			load_iq16(xn, p.iq + (size_t)t * p.hop + K1_LANE_SRC(lane));
-#endif
 			K1_STAMP(7);		/* loop overhead + stores of the previous iteration */
 			/* window (fft.cl:415-417); taps fetched as pairs */
-#if K1_LOAD16
 #pragma unroll
 			for (int k = 0; k < 8; k++) {	/* x[2k], x[2k+1] = elements 2L + 128k, 2L + 1 + 128k */
 				const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * k]);
 				x[2 * k]     = mul_bcast_lo(xn[2 * k], w);
 				x[2 * k + 1] = mul_bcast_hi(xn[2 * k + 1], w);
 			}
-#else
-#pragma unroll
-			for (int m = 0; m < 16; m += 2) {
-				v2f w;
-				w.x = win_tab[lane + 64 * m];
-				w.y = win_tab[lane + 64 * (m + 1)];
-				x[m]     = mul_bcast_lo(xn[m], w);
-				x[m + 1] = mul_bcast_hi(xn[m + 1], w);
-			}
-#endif
 
-#if K1_PREFETCH
 			/* prefetch the next spectrum this wave will process */
 			{
 				const bool last = (g0 + u + 1 == p.tile);
@@ -475,13 +374,12 @@ void k1_fft_bin(const K1Params p)
 				if (!last || tile + stride < ntiles)
 					load_iq16(xn, p.iq + (size_t)t_next * p.hop + K1_LANE_SRC(lane));
 			}
-#endif
 
 			K1_STAMP(0);		/* window (includes waiting for the prefetched IQ) + prefetch issue */
 			/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) --------
-			 * K1_LOAD16: this lane is virtual work-items i = 2L + v (elements i + 128j = x[2j + v]);
-			 * otherwise i = lane + 64v (elements lane + 64(v + 2j) = x[v + 2j]).  Either way item i
-			 * stores its outputs at e = 8i + jj; which lane runs which item is free. */
+			 * This lane is virtual work-items i = 2L + v (elements i + 128j = x[2j + v], as the 16-byte
+			 * loads deliver them).  Item i stores its outputs at e = 8i + jj; which lane runs which
+			 * item is free. */
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
 				v2f r[8];
@@ -491,11 +389,7 @@ void k1_fft_bin(const K1Params p)
 				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
-#if K1_LOAD16
 					buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
-#else
-					buf[(st1 ^ jj) + 512 * v] = r[R8_PERM(jj)];
-#endif
 			}
 			wave_lds_sync();
 #pragma unroll
@@ -537,11 +431,7 @@ void k1_fft_bin(const K1Params p)
 					r[0] = x[v];
 #pragma unroll
 					for (int j = 1; j < 8; j++)
-#if K1_TW3_LDS
-						r[j] = c_mul(x[v + 2 * j], tw3_tab[j - 1][lane]);
-#else
 						r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
-#endif
 					dft8(r, s12);
 #pragma unroll
 					for (int jj = 0; jj < 8; jj++)
@@ -607,7 +497,6 @@ void k1_fft_bin(const K1Params p)
 				}
 			}
 
-#if K1_UNIFORM
 #pragma unroll
 			for (int m = 0; m < 16; m++) {
 				/* Horner form of display.cl:149-150, in place (v_fma with the accumulator as destination:
@@ -622,17 +511,6 @@ void k1_fft_bin(const K1Params p)
 				for (int m = 0; m < 16; m++)
 					wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
 			}
-#else
-			const bool store_row = (t >= p.wf_first);
-			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++) {
-				live[m] = __builtin_fmaf(live[m], p.w, l2[m]);	/* Horner form of display.cl:149-150 */
-				vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
-				if (store_row)
-					wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
-			}
-#endif
 			K1_STAMP(6);		/* epilogue */
 		}
 
@@ -641,11 +519,7 @@ void k1_fft_bin(const K1Params p)
 		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
 #pragma unroll
 		for (int m = 0; m < 16; m++)
-#if K1_NT_BINS
-			__builtin_nontemporal_store(pack[m], &dst[64 * m]);
-#else
 			dst[64 * m] = pack[m];
-#endif
 	}
 
 	/* leave the log2 domain: pwr = log10|X| = l2 * log10(2)/2; an untouched max is exactly -1000 */
@@ -665,645 +539,6 @@ void k1_fft_bin(const K1Params p)
 		p.dbg[w * 8 + 5] = wall_clock64();
 	}
 #endif
-}
-
-/* ------------------------------------------------------------------------ */
-/* K1, two spectra ahead                                                      */
-/* ------------------------------------------------------------------------ */
-/* Same wave-per-spectrum mapping, arithmetic, LDS exchange and outputs as k1_fft_bin, with the changes that
- * come from measuring it: a wave of k1_fft_bin has ONE spectrum (8 KiB) of IQ in flight and drains the whole
- * vector-memory queue (`s_waitcnt vmcnt(0)`: the previous spectrum's stores included) before every spectrum;
- * at the ~3 us the memory system needs under load that round trip bounds it (2048 waves x 8 KiB / 3 us =
- * 5.5 TB/s at best, 4.5 TB/s with the compute in the loop) -- not bandwidth, and not the VALU (40 % busy).
- *   - the IQ of spectrum k+2 is requested while spectrum k is computed: two register sets, the loop unrolled by
- *     two so that neither is ever copied; 16 KiB per wave in flight;
- *   - the requests are inline-asm loads and the waits are hand-counted `s_waitcnt vmcnt(N)`: the vector-memory
- *     queue retires in order, so "at most N operations outstanding" with N = the operations issued AFTER the
- *     wanted request means exactly "the wanted request has landed", and the younger request and the bin-index
- *     stores stay in flight (the compiler's own counting has to assume that a conditional request or store did
- *     not happen and falls back to vmcnt(0));
- *   - the registers of the second set come from the pass-2/3 twiddles, which move to a work-group LDS table
- *     (14 ds_read_b64 per spectrum);
- *   - everything uniform over the wave (tile, spectrum index, row-store predicate) is forced into SGPRs, which
- *     turns 16 exec-mask save/restore sequences per spectrum into one scalar branch. */
-
-/* the 8 x 1 KiB of one spectrum: lane L gets elements (2L, 2L+1) + 128 q in set[q]; non-temporal (read once) */
-static __device__ __forceinline__ void iq_request(v4f (&q)[8], const float2 *src)
-{
-	const char *a = reinterpret_cast<const char *>(src);
-	const char *b = a + 4096;
-	asm volatile("global_load_dwordx4 %0, %1, off nt"             : "=v"(q[0]) : "v"(a) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(q[1]) : "v"(a) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(q[2]) : "v"(a) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(q[3]) : "v"(a) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off nt"             : "=v"(q[4]) : "v"(b) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(q[5]) : "v"(b) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(q[6]) : "v"(b) : "memory");
-	asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(q[7]) : "v"(b) : "memory");
-}
-
-/* The set's registers are tied to a point behind the hand-counted wait, so that no use of them can be
- * scheduled above it (volatile asm statements keep their order). */
-static __device__ __forceinline__ void iq_landed(v4f (&q)[8])
-{
-	asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
-	             :: "memory");
-}
-
-/* every value of x is computed before anything that follows (the next request reuses the set's registers:
- * without this the scheduler sinks window multiplies below the loads and the allocator pays with 32 copies) */
-static __device__ __forceinline__ void pin16(const v2f (&x)[16])
-{
-	asm volatile("" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
-	             "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]) : "memory");
-}
-
-template <bool WRITE_FFT, int DEPTH>	/* DEPTH: spectra requested ahead (2, or 1 = one register set: 208 VGPRs) */
-__global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
-void k1d_fft_bin(const K1Params p)
-{
-	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
-	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles */
-	__shared__ float win_tab[kN];			/* window */
-	__shared__ v2f   tw3_tab[7][64];		/* pass-3 twiddles [n-1][k] */
-	__shared__ v2f   tw2_tab[7][8];			/* pass-2 twiddles [n-1][k] */
-
-	const int lane   = threadIdx.x & 63;
-	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int ntiles = p.total / p.tile;
-	const int stride = gridDim.x * 4;		/* waves in the grid */
-	const int tile0  = blockIdx.x * 4 + wv;
-	const int T      = p.tile;
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-
-	for (int i = threadIdx.x; i < kN; i += 256)
-		win_tab[i] = p.win[i];
-	for (int i = threadIdx.x; i < 512; i += 256)
-		tw4_tab[i] = twg[kTw4Off + i];
-	for (int i = threadIdx.x; i < 7 * 64; i += 256)
-		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
-	if (threadIdx.x < 56)
-		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
-	__syncthreads();				/* the only block-wide barrier */
-
-	if (tile0 >= ntiles)
-		return;					/* whole wave leaves */
-
-	v2f *buf = lds[wv];
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
-
-	/* swizzled LDS addressing, as in k1_fft_bin */
-	const int rd_even = lane ^ ((lane >> 3) & 7);
-	const int rd_odd  = rd_even ^ 8;
-	const int st1a    = (16 * lane) ^ ((2 * lane) & 15);
-	const int st1b    = (16 * lane + 8) ^ ((2 * lane + 1) & 15);
-	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);
-
-	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
-	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
-	const float top = (float)(bk.nb - 1);
-
-	/* the k-th spectrum of this wave: tiles tile0, tile0 + stride, ... in order, T spectra each */
-	auto spectrum_of = [&](int k, int *tile_out) -> int {
-		const int j = k / T;
-		const int tile = tile0 + j * stride;
-		*tile_out = tile;
-		return tile * T + (k - j * T);
-	};
-	/* ALWAYS eight loads (the hand-counted waits rely on it): past the end of this wave's work the request
-	 * re-reads the launch's first spectrum (cache hits) and is never used */
-	auto request = [&](v4f (&q)[8], int k) {
-		int tile;
-		int t = spectrum_of(k, &tile);
-		if (tile >= ntiles)
-			t = 0;
-		iq_request(q, p.iq + (size_t)t * p.hop + 2 * lane);
-	};
-
-	float live[16], vmax[16];
-	uint32_t pack[16];
-
-	auto body = [&](v4f (&xq)[8], int k, int tile, int t, const bool odd) {
-		const int g = t - tile * T;		/* position in the tile */
-		const int u = g & 3;
-		v2f x[16];
-
-		if (g == 0) {
-#pragma unroll
-			for (int m = 0; m < 16; m++) {
-				live[m] = 0.0f;
-				vmax[m] = vmax_init;
-			}
-		}
-		if (u == 0) {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				pack[m] = 0;
-		}
-
-		/* Operations issued after this set's request: the other set's request (8) and, when the spectrum
-		 * before this one or the one before that closed a group of four (u == 3), its 16 bin-index stores.
-		 * (The rare row / partial stores only make the wait longer than needed.) */
-		if (DEPTH == 2) {
-			if (u < 2)
-				asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-		} else {
-			/* one set: only the 16 bin-index stores of a group that just closed are younger */
-			if (u == 0)
-				asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-			else
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
-		iq_landed(xq);
-
-		/* window (fft.cl:415-417); taps fetched as pairs */
-#pragma unroll
-		for (int q = 0; q < 8; q++) {	/* x[2q], x[2q+1] = elements 2L + 128q, 2L + 1 + 128q */
-			const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * q]);
-			x[2 * q]     = mul_bcast_lo(v2f{ xq[q].x, xq[q].y }, w);
-			x[2 * q + 1] = mul_bcast_hi(v2f{ xq[q].z, xq[q].w }, w);
-		}
-		/* this register set is free again: request the spectrum after next */
-		pin16(x);
-		request(xq, k + DEPTH);
-
-		/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) */
-#pragma unroll
-		for (int v = 0; v < 2; v++) {
-			v2f r[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++)
-				r[j] = x[v + 2 * j];
-			dft8(r, s12);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
-		}
-		wave_lds_sync();
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
-		wave_lds_sync();
-
-		/* ---- pass 2: radix 8, p = 8 (fft.cl:422-423) */
-		{
-			v2f tw2[7];
-#pragma unroll
-			for (int n = 0; n < 7; n++)
-				tw2[n] = tw2_tab[n][lane & 7];
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-				r[0] = x[v];
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
-				dft8(r, s12);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					buf[(st2 ^ (9 * jj)) + 512 * v] = r[R8_PERM(jj)];
-			}
-		}
-		wave_lds_sync();
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
-		wave_lds_sync();
-
-		/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426); the third exchange is register renaming */
-		{
-			v2f y[16];
-			v2f tw3[7];
-#pragma unroll
-			for (int n = 0; n < 7; n++)
-				tw3[n] = tw3_tab[n][lane];
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-				r[0] = x[v];
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
-				dft8(r, s12);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					y[jj + 8 * v] = r[R8_PERM(jj)];
-			}
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				x[m] = y[m];
-		}
-
-		/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) */
-#pragma unroll
-		for (int c = 0; c < 8; c++) {
-			v2f a = x[c];
-			v2f b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);
-			DFT2(a, b);
-			x[c] = a;
-			x[c + 8] = b;
-		}
-
-		if (WRITE_FFT) {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * m] = x[m];
-		}
-
-		/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) */
-		float    l2[16];
-		uint32_t amb = 0;
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			uint32_t ab;
-			const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
-			amb = amb > ab ? amb : ab;
-			pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
-		}
-		if (amb > __float_as_uint(bk.amb)) {
-#pragma unroll
-			for (int m = 0; m < 16; m++) {
-				const float v = __builtin_fmaf(bk.A, l2[m], bk.C);
-				const float r = __builtin_rintf(v);
-				const float a = __builtin_fmaf(__builtin_fabsf(l2[m]), bk.kappa, __builtin_fabsf(v - r));
-				if (!(a <= bk.amb)) {
-					const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
-					float nl2;
-					const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
-					pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
-					l2[m] = nl2;
-				}
-			}
-		}
-
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			/* Horner form of display.cl:149-150, in place (v_fma with the accumulator as destination) */
-			asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
-			vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
-		}
-		if (t >= p.wf_first) {				/* uniform: one scalar branch */
-			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
-		}
-		if (u == 3) {
-			/* 4 spectra x 1 column per dword, coalesced 256 B per instruction */
-			uint32_t *dst = p.bins + (size_t)(t >> 2) * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				dst[64 * m] = pack[m];
-		}
-		if (g == T - 1) {
-			/* leave the log2 domain; an untouched max is exactly -1000 */
-			float2 *pp = p.partial + (size_t)tile * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				pp[64 * m] = make_float2(live[m] * F_HALF_LOG10_2,
-				                         (vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
-		}
-	};
-
-	v4f xa[8], xb[8];
-	request(xa, 0);
-	if (DEPTH == 2)
-		request(xb, 1);
-	{
-		/* 16 stores behind the two requests, as every group of four spectra leaves them (the wait counts
-		 * of the first two spectra then hold from the start); the real indices overwrite these zeros */
-		uint32_t *dst = p.bins + (size_t)((tile0 * T) >> 2) * kN + lane;
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			dst[64 * m] = 0;
-	}
-	/* T is a multiple of 4, so neither a tile nor a group of four ends between the halves of an iteration */
-	for (int k = 0; ; k += 2) {
-		int tile;
-		const int t = spectrum_of(k, &tile);
-		if (tile >= ntiles)
-			break;
-		body(xa, k, tile, t, false);
-		if (DEPTH == 2)
-			body(xb, k + 1, tile, t + 1, true);
-		else
-			body(xa, k + 1, tile, t + 1, true);
-	}
-	/* the two requests still in flight target registers: they must land before the wave ends */
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-/* ------------------------------------------------------------------------ */
-/* K1, three waves per SIMD                                                    */
-/* ------------------------------------------------------------------------ */
-/* K1 is bound by the issue rate of its own instruction stream at two waves per SIMD: the
- * VALU pipe needs ~2270 cycles per spectrum and gets a spectrum every ~4200, because two waves cannot cover
- * each other's LDS round trips and dependent chains.  A third wave needs <= 168 registers per lane.  What goes:
- *   - the 32 registers of the next spectrum's IQ: the spectrum is fetched by LDS-DMA (global_load_lds_dwordx4,
- *     8 x 1 KiB, non-temporal) straight into the wave's exchange slab, issued once the current spectrum no longer
- *     needs the slab (after its last exchange read; passes 3-4 and the epilogue run out of registers) -- no second
- *     slab, so 12 waves x 8 KiB still fit a CU beside the tables and K2;
- *   - the 28 registers of the pass-2/3 twiddles: work-group LDS tables (as in k1d_fft_bin).
- * Pass 1 reads its inputs back from the slab (8 ds_read_b128 per lane: elements (2L, 2L+1) + 128 q land at byte
- * 16 L + 1024 q, which is exactly the register layout of the 16-byte loads).  Work-groups of 6 waves (two per CU:
- * 2 x 60 KiB of LDS + 32 KiB for K2).  Same arithmetic, same outputs as k1_fft_bin. */
-template <bool WRITE_FFT>
-__global__ __launch_bounds__(384, 3)
-void k1t_fft_bin(const K1Params p)
-{
-	__shared__ v2f   lds[6][kN];			/* 8 KiB slab per wave: landing zone AND exchange buffer */
-	__shared__ v2f   tw4_tab[512];
-	__shared__ float win_tab[kN];
-	__shared__ v2f   tw3_tab[7][64];
-	__shared__ v2f   tw2_tab[7][8];
-
-	const int lane   = threadIdx.x & 63;
-	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int ntiles = p.total / p.tile;
-	const int stride = gridDim.x * 6;		/* waves in the grid */
-	const int tile0  = blockIdx.x * 6 + wv;
-	const int T      = p.tile;
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-
-	for (int i = threadIdx.x; i < kN; i += 384)
-		win_tab[i] = p.win[i];
-	for (int i = threadIdx.x; i < 512; i += 384)
-		tw4_tab[i] = twg[kTw4Off + i];
-	for (int i = threadIdx.x; i < 7 * 64; i += 384)
-		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
-	if (threadIdx.x < 56)
-		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
-	__syncthreads();				/* the only block-wide barrier */
-
-	if (tile0 >= ntiles)
-		return;					/* whole wave leaves */
-
-	v2f *buf = lds[wv];
-	const uint32_t slab = (uint32_t)reinterpret_cast<uintptr_t>(buf) + 16 * lane;	/* LDS byte address of this lane's pair */
-	const uint32_t tw3_addr = (uint32_t)reinterpret_cast<uintptr_t>(&tw3_tab[0][lane]);	/* [n][lane]: 512 B per n */
-	const uint32_t tw4_addr = (uint32_t)reinterpret_cast<uintptr_t>(&tw4_tab[lane]);	/* [lane + 64 c]: 512 B per c */
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
-
-	const int rd_even = lane ^ ((lane >> 3) & 7);
-	const int rd_odd  = rd_even ^ 8;
-	const int st1a    = (16 * lane) ^ ((2 * lane) & 15);
-	const int st1b    = (16 * lane + 8) ^ ((2 * lane + 1) & 15);
-	const int st2     = ((64 * (lane >> 3)) + (lane & 7)) ^ (lane & 8);
-
-	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
-	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
-	const float top = (float)(bk.nb - 1);
-
-	auto spectrum_of = [&](int k, int *tile_out) -> int {
-		const int j = k / T;
-		const int tile = tile0 + j * stride;
-		*tile_out = tile;
-		return tile * T + (k - j * T);
-	};
-	/* ALWAYS eight requests (the hand-counted wait relies on it); past the end: the launch's first spectrum */
-	auto request = [&](int k) {
-		int tile;
-		int t = spectrum_of(k, &tile);
-		if (tile >= ntiles)
-			t = 0;
-		const float2 *src = p.iq + (size_t)t * p.hop + 2 * lane;
-		float *dst = reinterpret_cast<float *>(buf);
-		__builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);
-		__builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 2);
-		__builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 2);
-		__builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 2);
-		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 0, 2);
-		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 1024, 2);
-		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 2048, 2);
-		__builtin_amdgcn_global_load_lds(src + 512, dst + 1024, 16, 3072, 2);
-	};
-
-	float live[16], vmax[16];
-	uint32_t pack[16];
-
-	request(0);
-	{
-		/* 16 stores behind the first request, as every group of four spectra leaves them behind the request of
-		 * its successor (the wait count of a group's first spectrum then holds from the start) */
-		uint32_t *dst = p.bins + (size_t)((tile0 * T) >> 2) * kN + lane;
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			dst[64 * m] = 0;
-	}
-
-	for (int k = 0; ; k++) {
-		int tile;
-		const int t = spectrum_of(k, &tile);
-		if (tile >= ntiles)
-			break;
-		const int g = t - tile * T;		/* position in the tile */
-		const int u = g & 3;
-		v2f x[16];
-
-		if (g == 0) {
-#pragma unroll
-			for (int m = 0; m < 16; m++) {
-				live[m] = 0.0f;
-				vmax[m] = vmax_init;
-			}
-		}
-		if (u == 0) {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				pack[m] = 0;
-		}
-
-		/* younger than this spectrum's request: the 16 bin-index stores of the group that just closed (the
-		 * rare row / partial stores only make the wait longer than needed) */
-		if (u == 0)
-			asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-		else
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		{
-			v4f q[8];
-			asm volatile("ds_read_b128 %0, %8\n\t"
-			             "ds_read_b128 %1, %8 offset:1024\n\t"
-			             "ds_read_b128 %2, %8 offset:2048\n\t"
-			             "ds_read_b128 %3, %8 offset:3072\n\t"
-			             "ds_read_b128 %4, %8 offset:4096\n\t"
-			             "ds_read_b128 %5, %8 offset:5120\n\t"
-			             "ds_read_b128 %6, %8 offset:6144\n\t"
-			             "ds_read_b128 %7, %8 offset:7168\n\t"
-			             "s_waitcnt lgkmcnt(0)"
-			             : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-			             : "v"(slab) : "memory");
-			/* window (fft.cl:415-417); taps fetched as pairs */
-#pragma unroll
-			for (int j = 0; j < 8; j++) {
-				const v2f w = *reinterpret_cast<const v2f *>(&win_tab[2 * lane + 128 * j]);
-				x[2 * j]     = mul_bcast_lo(v2f{ q[j].x, q[j].y }, w);
-				x[2 * j + 1] = mul_bcast_hi(v2f{ q[j].z, q[j].w }, w);
-			}
-		}
-
-		/* ---- pass 1: radix 8, p = 1, no twiddle (fft.cl:419-420) */
-#pragma unroll
-		for (int v = 0; v < 2; v++) {
-			v2f r[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++)
-				r[j] = x[v + 2 * j];
-			dft8(r, s12);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				buf[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
-		}
-		wave_lds_sync();
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
-		wave_lds_sync();
-
-		/* ---- pass 2: radix 8, p = 8 (fft.cl:422-423) */
-		{
-			v2f tw2[7];
-#pragma unroll
-			for (int n = 0; n < 7; n++)
-				tw2[n] = tw2_tab[n][lane & 7];
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-				r[0] = x[v];
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
-				dft8(r, s12);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					buf[(st2 ^ (9 * jj)) + 512 * v] = r[R8_PERM(jj)];
-			}
-		}
-		wave_lds_sync();
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = buf[((m & 1) ? rd_odd : rd_even) + 64 * m];
-		wave_lds_sync();
-		/* the slab is not touched again by this spectrum (the third exchange is register renaming): it takes the
-		 * next one now.  The table reads below are asm so that the compiler does not drain the request in front
-		 * of them (it cannot tell an LDS-DMA target from any other LDS address). */
-		pin16(x);
-		request(k + 1);
-
-		/* ---- pass 3: radix 8, p = 64 (fft.cl:425-426); the third exchange is register renaming */
-		{
-			v2f y[16];
-			v2f tw3[7];
-			asm volatile("ds_read_b64 %0, %7\n\t"
-			             "ds_read_b64 %1, %7 offset:512\n\t"
-			             "ds_read_b64 %2, %7 offset:1024\n\t"
-			             "ds_read_b64 %3, %7 offset:1536\n\t"
-			             "ds_read_b64 %4, %7 offset:2048\n\t"
-			             "ds_read_b64 %5, %7 offset:2560\n\t"
-			             "ds_read_b64 %6, %7 offset:3072\n\t"
-			             "s_waitcnt lgkmcnt(0)"
-			             : "=&v"(tw3[0]), "=&v"(tw3[1]), "=&v"(tw3[2]), "=&v"(tw3[3]), "=&v"(tw3[4]), "=&v"(tw3[5]), "=&v"(tw3[6])
-			             : "v"(tw3_addr) : "memory");
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-				r[0] = x[v];
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
-				dft8(r, s12);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					y[jj + 8 * v] = r[R8_PERM(jj)];
-			}
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				x[m] = y[m];
-		}
-
-		/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) */
-		{
-			v2f tw4[8];
-			asm volatile("ds_read_b64 %0, %8\n\t"
-			             "ds_read_b64 %1, %8 offset:512\n\t"
-			             "ds_read_b64 %2, %8 offset:1024\n\t"
-			             "ds_read_b64 %3, %8 offset:1536\n\t"
-			             "ds_read_b64 %4, %8 offset:2048\n\t"
-			             "ds_read_b64 %5, %8 offset:2560\n\t"
-			             "ds_read_b64 %6, %8 offset:3072\n\t"
-			             "ds_read_b64 %7, %8 offset:3584\n\t"
-			             "s_waitcnt lgkmcnt(0)"
-			             : "=&v"(tw4[0]), "=&v"(tw4[1]), "=&v"(tw4[2]), "=&v"(tw4[3]), "=&v"(tw4[4]), "=&v"(tw4[5]), "=&v"(tw4[6]), "=&v"(tw4[7])
-			             : "v"(tw4_addr) : "memory");
-#pragma unroll
-			for (int c = 0; c < 8; c++) {
-				v2f a = x[c];
-				v2f b = c_mul(x[c + 8], tw4[c]);
-				DFT2(a, b);
-				x[c] = a;
-				x[c + 8] = b;
-			}
-		}
-
-		if (WRITE_FFT) {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * kN + lane + 64 * m] = x[m];
-		}
-
-		/* ---- epilogue: log-power, exact bin (display.cl:136,161-168) */
-		float    l2[16];
-		uint32_t amb = 0;
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			uint32_t ab;
-			const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
-			amb = amb > ab ? amb : ab;
-			pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
-		}
-		if (amb > __float_as_uint(bk.amb)) {
-#pragma unroll
-			for (int m = 0; m < 16; m++) {
-				const float v = __builtin_fmaf(bk.A, l2[m], bk.C);
-				const float r = __builtin_rintf(v);
-				const float a = __builtin_fmaf(__builtin_fabsf(l2[m]), bk.kappa, __builtin_fabsf(v - r));
-				if (!(a <= bk.amb)) {
-					const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
-					float nl2;
-					const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
-					pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
-					l2[m] = nl2;
-				}
-			}
-		}
-#pragma unroll
-		for (int m = 0; m < 16; m++) {
-			asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
-			vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
-		}
-		if (t >= p.wf_first) {				/* uniform: one scalar branch */
-			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				wf_row[64 * m] = l2[m] * F_HALF_LOG10_2;	/* display.cl:142-146 */
-		}
-		if (u == 3) {
-			uint32_t *dst = p.bins + (size_t)(t >> 2) * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				dst[64 * m] = pack[m];
-		}
-		if (g == T - 1) {
-			float2 *pp = p.partial + (size_t)tile * kN + lane;
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				pp[64 * m] = make_float2(live[m] * F_HALF_LOG10_2,
-				                         (vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
-		}
-	}
-	/* the request past the last spectrum still targets this wave's LDS: it must land before the wave ends */
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 /* ------------------------------------------------------------------------ */
@@ -2390,8 +1625,11 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 	constexpr int N = 65536;
 	static bool attr_set = false;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+		if (e == hipSuccess)
+			e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+		if (e != hipSuccess)
+			return e;
 		attr_set = true;
 	}
 	if (p0.sync && p0.tile >= 2 && !(p0.tile & 1) && p0.total / p0.tile < (1 << 20)) {	/* (tile index: 20 bits of the claim word) */
@@ -2399,10 +1637,13 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 		constexpr size_t lds_f = ((size_t)16 * 513 + (8 + 64) * 7 + 7 * 64 + 8 * 7 * 64 + 64 * 64) * sizeof(float2);
 		static bool attr_f = false;
 		if (!attr_f) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_fused<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+			const void *fn[4] = { reinterpret_cast<const void *>(k1h_fused<false, false>), reinterpret_cast<const void *>(k1h_fused<true, false>),
+			                      reinterpret_cast<const void *>(k1h_fused<false, true>), reinterpret_cast<const void *>(k1h_fused<true, true>) };
+			for (int i = 0; i < 4; i++) {
+				const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+				if (e != hipSuccess)
+					return e;
+			}
 			attr_f = true;
 		}
 		if (hipMemsetAsync(p0.sync, 0, 64 * 64 * sizeof(uint32_t), s) != hipSuccess)	/* the counters; not the error word behind them */
@@ -2478,10 +1719,13 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;	/* exchange slab + twiddle table + window: 160 KiB */
 		int blocks = tiles < 256 ? tiles : 256;		/* one work-group (16 waves, 128 VGPRs) per CU */
 		if (!attr_set) {
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
-			                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, true>),
-			                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e == hipSuccess)
+				e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, true>),
+				                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e != hipSuccess)
+				return e;
 			attr_set = true;
 		}
 		if (p.fft_out)
@@ -2497,33 +1741,6 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			hipLaunchKernelGGL(k1v2_fft_bin<true>, dim3(blocks), dim3(128), 0, s, p);
 		else
 			hipLaunchKernelGGL(k1v2_fft_bin<false>, dim3(blocks), dim3(128), 0, s, p);
-		return hipGetLastError();
-	}
-	if (p.variant == 7) {
-		int blocks = (tiles + 5) / 6;
-		if (blocks > 512)
-			blocks = 512;			/* two 6-wave work-groups per CU */
-		if (p.fft_out)
-			hipLaunchKernelGGL(k1t_fft_bin<true>, dim3(blocks), dim3(384), 0, s, p);
-		else
-			hipLaunchKernelGGL(k1t_fft_bin<false>, dim3(blocks), dim3(384), 0, s, p);
-		return hipGetLastError();
-	}
-	if (p.variant == 5 || p.variant == 6) {
-		int blocks = (tiles + 3) / 4;
-		if (blocks > kK1MaxBlocks)
-			blocks = kK1MaxBlocks;
-		if (p.variant == 5) {
-			if (p.fft_out)
-				hipLaunchKernelGGL((k1d_fft_bin<true, 2>), dim3(blocks), dim3(256), 0, s, p);
-			else
-				hipLaunchKernelGGL((k1d_fft_bin<false, 2>), dim3(blocks), dim3(256), 0, s, p);
-		} else {
-			if (p.fft_out)
-				hipLaunchKernelGGL((k1d_fft_bin<true, 1>), dim3(blocks), dim3(256), 0, s, p);
-			else
-				hipLaunchKernelGGL((k1d_fft_bin<false, 1>), dim3(blocks), dim3(256), 0, s, p);
-		}
 		return hipGetLastError();
 	}
 	int blocks = (tiles + 3) / 4;
@@ -2649,11 +1866,7 @@ void k2_count(const K2Params p)
 			uint32_t v[K2_INFLIGHT];
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++)
-#if K2_NT_LOAD
-				v[u] = __builtin_nontemporal_load(&src[(q + NW * u) * n + lane]);
-#else
 				v[u] = src[(q + NW * u) * n + lane];
-#endif
 #pragma unroll
 			for (int u = 0; u < K2_INFLIGHT; u++) {
 				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
@@ -2706,24 +1919,6 @@ void k2_count(const K2Params p)
 		/* the LDS image as it is: [bin][32] packed pairs, one contiguous block per work-group
 		 * (32 KiB at 256 bins); K3 unpacks */
 		uint32_t *d = reinterpret_cast<uint32_t *>(p.hc16) + ((size_t)c * (p.n / 64) + blockIdx.x) * nb * 32;
-		if (NW == 4 && p.wavebits) {
-			/* lean sparse hand-off (N = 1024): a wave's step covers two bin rows (2 wv + 8 k and the next); the ballot
-			 * of "dword != 0" says which of the two has counts -- only those are stored, and the 2 x 32 answers are the
-			 * wave's 64 row bits for K3 */
-			unsigned long long bits = 0;
-			int kk = 0;
-			for (int i = tid; i < nb * 32; i += 64 * NW, kk++) {
-				const uint32_t v = h[i];
-				const unsigned long long bal = __ballot(v != 0);
-				const uint32_t b0 = (uint32_t)bal != 0, b1 = (uint32_t)(bal >> 32) != 0;
-				bits |= (unsigned long long)(b0 | (b1 << 1)) << (2 * kk);
-				if ((lane & 32) ? b1 : b0)
-					d[i] = v;
-			}
-			if (lane == 0)
-				p.wavebits[((size_t)blockIdx.x * NW + wv) * p.mask_stride + c] = bits;
-			return;
-		}
 		if (p.rowmask) {
 			/* sparse hand-off: only the bin rows with a count are stored (a wave covers two rows of 32 dwords per
 			 * step), one bit per row tells K3 which; with noise-like input 4 rows in 5 are empty */
@@ -3022,23 +2217,14 @@ void k3_merge(const K3Params p)
 			const int hidx = bin * p.n + slab * 64 + col;
 			const float hv0 = p.hist[hidx];
 			float hv = hv0;
-			for (int f0 = 0; f0 < p.n_batches; f0 += 64) {
-				/* K2's row bits of this (slab, bin) row for 64 batches: lane l asks for batch f0 + l (one 512-byte request) */
-				unsigned long long m = ~0ull;
-				if (p.wavebits) {
-					const int fl = f0 + (threadIdx.x & 63);
-					const unsigned long long wb = (fl < p.n_batches)
-					        ? p.wavebits[((size_t)slab * 4 + ((bin >> 1) & 3)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0ull;
-					m = __ballot((wb >> (2 * (bin >> 3) + (bin & 1))) & 1ull);
-				}
-				const int fe = (p.n_batches - f0 < 64) ? p.n_batches : f0 + 64;
-				int f = f0;
+			{
+				const int fe = p.n_batches;
+				int f = 0;
 				for (; f + 8 <= fe; f += 8) {
 					uint32_t hc[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++)
-						hc[u] = ((m >> (f + u - f0)) & 1ull)
-						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]) : 0u;
+						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
@@ -3050,7 +2236,7 @@ void k3_merge(const K3Params p)
 					}
 				}
 				for (; f < fe; f++) {
-					const uint32_t hc = ((m >> (f - f0)) & 1ull) ? (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid] : 0u;
+					const uint32_t hc = (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid];
 					if (!((hv <= 0.01f) && (hc == 0))) {
 						const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
 						hv = (hv - de.x) * de.y + de.x;
@@ -3216,244 +2402,6 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 }
 
 /* ------------------------------------------------------------------------ */
-/* K23: counts + state update per 4-column strip                             */
-/* ------------------------------------------------------------------------ */
-
-/* The state update of a cell needs the cell's count of EVERY batch, in order (display.cl:217-254 is not
- * composable across batches), and a count needs all spectra of a batch -- which K1 spreads over the chip.
- * K2/K3 therefore handed 16-bit counts through memory: 0.5 B per sample written and read again, 9 % of
- * what the pipeline moves.  Here the work-group that owns a cell also counts it: 256 work-groups of 4
- * columns, each walking the launch's batches in order.
- *   counting   thread (r, c) = (tid >> 2, tid & 3) reads the dword of quad-row r, column c: 16 B per
- *              quad-row and work-group; the 8 work-groups that share a 128-byte line are placed on the same
- *              XCD (work-group b runs on XCD b % 8), so the line is fetched from HBM once and served from
- *              that XCD's L2 to the others.  ds_add on cnt[bin][4]; lanes of one column that meet in a bin
- *              are serialised by the LDS, which is the price of a pure tone only.
- *   update     the thread that owns a cell reads and clears its counter: no zeroing pass; hist values stay in
- *              registers for the whole launch (4 per thread at 256 bins); (d, e) per count from the host's
- *              table in LDS (host powf = the oracle's binding).
- *   columns    live sum = tile partials x weights in a fixed order (deterministic floats), live EMA and
- *              max-hold with decay (display.cl:186-214,257-310) by one thread per column.
- * 31 VGPRs, <= 20 KiB LDS: one such work-group fits beside the K1 work-groups of a CU. */
-#ifndef K23_DEPTH
-#define K23_DEPTH 4			/* batches in flight per thread (6 registers each) */
-#endif
-template <int CPT>		/* cells per thread: n_bins * 4 / 256, rounded up (4 at 256 bins) */
-__global__ __launch_bounds__(256)
-void k23_strip(const K23Params p)
-{
-	extern __shared__ uint32_t cnt_all[];			/* 2 x [n_bins][4]: batches alternate between them */
-	__shared__ float2 rise_lds[1025];
-	__shared__ float red_s[2][4][4], red_m[2][4][4];	/* [batch parity][wave][column] */
-
-	/* These four waves sit beside K1's eight on the CU and the batches of a launch are a serial chain through
-	 * them (~100 instructions per batch and wave): they go first whenever they have something to issue. */
-	__builtin_amdgcn_s_setprio(3);
-
-	const int tid = threadIdx.x;
-	const int r = tid >> 2, c = tid & 3;
-	const int wv = tid >> 6;
-	/* strips of one 128-byte line (32 columns) share an XCD: b = 8 i + x -> strip = (strips / 8) x + i */
-	const int strips = p.n >> 2;
-	const int b = blockIdx.x;
-	const int strip = (strips >= 8 && (strips & 7) == 0) ? (strips >> 3) * (b & 7) + (b >> 3) : b;
-	const int x0 = strip * 4;
-	const int ncell = p.n_bins * 4;
-	const int qrows = p.batch >> 2;				/* quad-rows per batch */
-	const int tiles = p.batch / p.tile;
-	const uint32_t n = (uint32_t)p.n;
-
-	for (int i = tid; i <= p.batch && i < 1025; i += 256)
-		rise_lds[i] = p.rise[i];
-	for (int i = tid; i < 2 * ncell; i += 256)
-		cnt_all[i] = 0;
-
-	/* this thread's cells: cell = tid + 256 j -> (bin, col) = (cell >> 2, cell & 3); offset of cell j in a
-	 * [bin][N] array = cell0 + 64 N j */
-	const uint32_t cell0 = (uint32_t)(tid >> 2) * n + x0 + c;
-	float hv[CPT];
-#pragma unroll
-	for (int j = 0; j < CPT; j++)
-		hv[j] = (tid + 256 * j < ncell) ? p.hist[cell0 + 64 * n * j] : 0.0f;
-	/* column state (threads 0..3) */
-	const int half = p.n >> 1;
-	float live = 0.0f, mh = 0.0f;
-	if (tid < 4) {
-		const int xi = (x0 + c) ^ half;			/* fft-shifted vertex index, display.cl:200-201 */
-		live = p.spectrum[xi].y;
-		mh   = p.spectrum[p.n + xi].y;
-	}
-	__syncthreads();
-
-	/* This thread's share of a batch: the dwords of quad-rows r, r + 64, r + 128, r + 192 (those below
-	 * qrows) in column c, and the partial of tile r.  Shares are requested K23_DEPTH - 1 batches ahead into a
-	 * ring of register sets, because under load a request takes ~3 us to come back and the batches are a serial
-	 * chain: with one batch of look-ahead the chain ran at 2.3 us per batch.  As in k1d_fft_bin the requests
-	 * are inline-asm loads and the waits hand-counted: every thread issues exactly 5 requests per batch (clamped,
-	 * never skipped), so "at most 5 (K23_DEPTH - 1) outstanding" means "this batch has landed".
-	 * The counters alternate between two arrays, so one barrier per batch is enough (a counter is cleared by its
-	 * owner two barriers before it is counted into again). */
-	uint32_t voff[4];
-	bool     vok[4];
-#pragma unroll
-	for (int u = 0; u < 4; u++) {
-		vok[u]  = (r + 64 * u) < qrows;
-		voff[u] = ((uint32_t)(vok[u] ? r + 64 * u : 0) * n + x0 + c) * 4;		/* bytes */
-	}
-	const bool pok = r < tiles;
-	const uint32_t poff = ((uint32_t)(pok ? r : 0) * n + x0 + c) * 8;		/* bytes */
-	const float pw = __builtin_amdgcn_exp2f(p.log2_w * (float)(p.batch - (r + 1) * p.tile));	/* (1-a)^(B-1-t_last) */
-
-	struct Share { uint32_t v[4]; v2f pv; };
-	Share ring[K23_DEPTH];
-	auto request = [&](Share &sh, int fb) {
-		const int fc = fb < p.n_batches ? fb : p.n_batches - 1;
-		const uint32_t *s1 = p.bins + (size_t)fc * qrows * n;			/* uniform bases, 32-bit lane offsets */
-		const float2 *p1 = p.partial + (size_t)fc * tiles * n;
-		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[0]) : "v"(voff[0]), "s"(s1) : "memory");
-		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[1]) : "v"(voff[1]), "s"(s1) : "memory");
-		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[2]) : "v"(voff[2]), "s"(s1) : "memory");
-		asm volatile("global_load_dword %0, %1, %2" : "=v"(sh.v[3]) : "v"(voff[3]), "s"(s1) : "memory");
-		asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(sh.pv) : "v"(poff), "s"(p1) : "memory");
-	};
-	auto landed = [&](Share &sh) {
-		asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * (K23_DEPTH - 1)) : "memory");
-		asm volatile("" : "+v"(sh.v[0]), "+v"(sh.v[1]), "+v"(sh.v[2]), "+v"(sh.v[3]), "+v"(sh.pv) :: "memory");
-	};
-
-	auto step = [&](Share &sh, int f) {
-		uint32_t *cnt = cnt_all + (f & 1) * ncell;
-		uint32_t *cntc = cnt + c;
-		landed(sh);
-		uint32_t vcur[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++)
-			vcur[u] = sh.v[u];
-		const float px = sh.pv.x, py = sh.pv.y;
-		request(sh, f + K23_DEPTH);		/* this set is free again */
-		/* ---- count (display.cl:161-177) ---------------------------------- */
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			if (vok[u]) {
-				atomicAdd(&cntc[((vcur[u]      ) & 0xff) * 4], 1u);
-				atomicAdd(&cntc[((vcur[u] >>  8) & 0xff) * 4], 1u);
-				atomicAdd(&cntc[((vcur[u] >> 16) & 0xff) * 4], 1u);
-				atomicAdd(&cntc[((vcur[u] >> 24)       ) * 4], 1u);
-			}
-		}
-		/* ---- live sum / max of the batch from the tile partials (display.cl:139,149-150): the 16 tiles of a
-		 * wave's lanes with the same column by a fixed butterfly (deterministic), the 4 waves below */
-		{
-			float sv = 0.0f, m = -1000.0f;
-			if (pok) {
-				sv = px * pw;
-				m = py;
-			}
-			if (tiles > 64) {			/* tiles shorter than 16 spectra: the rest, in place */
-				const float2 *pp = p.partial + (size_t)f * tiles * n + x0 + c;
-				for (int j = r + 64; j < tiles; j += 64) {
-					const float2 v = pp[(uint32_t)j * n];
-					const int t_last = (j + 1) * p.tile - 1;
-					sv += v.x * __builtin_amdgcn_exp2f(p.log2_w * (float)(p.batch - 1 - t_last));
-					m = (m < v.y) ? v.y : m;
-				}
-			}
-#pragma unroll
-			for (int d = 4; d < 64; d <<= 1) {
-				const float so = __shfl_xor(sv, d, 64);
-				const float mo = __shfl_xor(m, d, 64);
-				sv += so;
-				m = (m < mo) ? mo : m;
-			}
-			if ((tid & 63) < 4) {
-				red_s[f & 1][wv][c] = sv;
-				red_m[f & 1][wv][c] = m;
-			}
-		}
-		__syncthreads();
-
-		/* ---- rise / decay of this thread's cells (display.cl:217-254), branch-free ---- */
-		uint32_t hc[CPT];
-#pragma unroll
-		for (int j = 0; j < CPT; j++)
-			hc[j] = (tid + 256 * j < ncell) ? cnt[tid + 256 * j] : 0;
-#pragma unroll
-		for (int j = 0; j < CPT; j++)
-			if (tid + 256 * j < ncell)
-				cnt[tid + 256 * j] = 0;
-#pragma unroll
-		for (int j = 0; j < CPT; j++) {
-			const float2 de = rise_lds[hc[j]];
-			float h = (hv[j] - de.x) * de.y + de.x;			/* display.cl:247 */
-			h = (h < 0.0f) ? 0.0f : h;				/* clamp, display.cl:250 */
-			h = (1.0f < h) ? 1.0f : h;
-			hv[j] = ((hv[j] <= 0.01f) && (hc[j] == 0)) ? hv[j] : h;	/* display.cl:237-238 */
-		}
-		if (f == p.n_batches - 1) {
-#pragma unroll
-			for (int j = 0; j < CPT; j++)
-				if (tid + 256 * j < ncell)
-					p.hc_export[cell0 + 64 * n * j] = hc[j];
-		}
-		/* ---- live EMA (display.cl:186-214), max-hold with decay (display.cl:257-310) */
-		if (tid < 4) {
-			float sum = red_s[f & 1][0][c], mx = red_m[f & 1][0][c];
-#pragma unroll
-			for (int w = 1; w < 4; w++) {				/* fixed order */
-				sum += red_s[f & 1][w][c];
-				mx = (mx < red_m[f & 1][w][c]) ? red_m[f & 1][w][c] : mx;
-			}
-			if (!__builtin_isfinite(live))
-				live = sum / 16.0f;			/* display.cl:206-207 */
-			live = live * p.live_decay + sum * p.alpha;	/* display.cl:210-211 */
-			if (!__builtin_isfinite(mh))
-				mh = -3.402823466e+38f;			/* display.cl:290-291 */
-			mh = mh * 0.999f + 0.001f * live;		/* display.cl:303 */
-			mh = (mh < mx) ? mx : mh;			/* display.cl:304-305 */
-		}
-	};
-
-	/* the state loads above are the compiler's own: used (waited for) here, not at their first use inside
-	 * the loop, where the compiler's vmcnt(0) would drain the request ring once per trip */
-#pragma unroll
-	for (int j = 0; j < CPT; j++)
-		asm volatile("" :: "v"(hv[j]));
-	asm volatile("" :: "v"(live), "v"(mh));
-#pragma unroll
-	for (int d = 0; d < K23_DEPTH; d++)
-		request(ring[d], d);
-#pragma unroll 1
-	for (int f0 = 0; f0 < p.n_batches; f0 += K23_DEPTH) {
-#pragma unroll
-		for (int d = 0; d < K23_DEPTH; d++)
-			if (f0 + d < p.n_batches)		/* uniform */
-				step(ring[d], f0 + d);
-	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* the look-ahead requests past the last batch */
-
-#pragma unroll
-	for (int j = 0; j < CPT; j++)
-		if (tid + 256 * j < ncell)
-			p.hist[cell0 + 64 * n * j] = hv[j];
-	if (tid < 4) {
-		const int xi = (x0 + c) ^ half;
-		const float vx = ((float)xi / (float)half) - 1.0f;	/* display.cl:209,293 */
-		p.spectrum[xi]       = make_float2(vx, live);
-		p.spectrum[p.n + xi] = make_float2(vx, mh);
-	}
-}
-
-hipError_t launch_k23(const K23Params &p, hipStream_t s)
-{
-	const size_t lds = (size_t)2 * p.n_bins * 4 * sizeof(uint32_t);
-	if (p.n_bins <= 256)
-		hipLaunchKernelGGL(k23_strip<4>, dim3(p.n / 4), dim3(256), lds, s, p);
-	else
-		hipLaunchKernelGGL(k23_strip<8>, dim3(p.n / 4), dim3(256), lds, s, p);
-	return hipGetLastError();
-}
-
-/* ------------------------------------------------------------------------ */
 
 __global__ void k_fill(float *dst, float value, size_t n)
 {
@@ -3465,7 +2413,7 @@ __global__ void k_fill(float *dst, float value, size_t n)
  * store -- clear bit in its row mask -- are zero) */
 __global__ __launch_bounds__(256)
 void k_export_hc16(const uint16_t *__restrict__ hc16, const uint32_t *__restrict__ rowmask, int mask_words, int mask_stride,
-                   uint32_t *__restrict__ out, int n_bins, int n, const unsigned long long *__restrict__ wavebits)
+                   uint32_t *__restrict__ out, int n_bins, int n)
 {
 	const size_t cells = (size_t)n_bins * n;
 	for (size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x; gid < cells; gid += (size_t)gridDim.x * 256) {
@@ -3473,19 +2421,16 @@ void k_export_hc16(const uint16_t *__restrict__ hc16, const uint32_t *__restrict
 		const int rem = (int)(gid - (size_t)slab * n_bins * 64);
 		const int bin = rem >> 6;
 		const int col = ((rem & 63) >> 1) + ((rem & 1) << 5);
-		bool stored = !rowmask || ((rowmask[((size_t)slab * mask_words + (bin >> 5)) * mask_stride] >> (bin & 31)) & 1u);
-		if (wavebits)
-			stored = (wavebits[((size_t)slab * 4 + ((bin >> 1) & 3)) * mask_stride] >> (2 * (bin >> 3) + (bin & 1))) & 1ull;
+		const bool stored = !rowmask || ((rowmask[((size_t)slab * mask_words + (bin >> 5)) * mask_stride] >> (bin & 31)) & 1u);
 		out[(size_t)bin * n + slab * 64 + col] = stored ? hc16[gid] : 0u;
 	}
 }
 
-hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s,
-                              const unsigned long long *wavebits)
+hipError_t launch_export_hc16(const uint16_t *hc16, const uint32_t *rowmask, int mask_words, int mask_stride, uint32_t *out, int n_bins, int n, hipStream_t s)
 {
 	size_t blocks = ((size_t)n_bins * n + 255) / 256;
 	if (blocks > 8192) blocks = 8192;
-	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, rowmask, mask_words, mask_stride, out, n_bins, n, wavebits);
+	hipLaunchKernelGGL(k_export_hc16, dim3((unsigned)blocks), dim3(256), 0, s, hc16, rowmask, mask_words, mask_stride, out, n_bins, n);
 	return hipGetLastError();
 }
 

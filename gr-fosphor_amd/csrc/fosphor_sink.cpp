@@ -16,84 +16,108 @@
 namespace fosphor_amd {
 
 /* ------------------------------------------------------------------------ */
-/* fifo (lib/fifo.cc)                                                       */
+/* fifo: the surface of lib/fifo.h:20-46 on an SPSC counter ring               */
 /* ------------------------------------------------------------------------ */
+/* The producer owns committed_, the consumer owns discarded_; each side only ever reads the other's counter.
+ * A side that finds too little room / data registers as a sleeper and re-checks under sleep_mutex_ before it
+ * waits, and a side that moves its counter takes that mutex only if somebody sleeps -- so the streaming case
+ * (neither side blocked) costs two atomic operations per region and no lock. */
 
 fifo::fifo(int length, bool pinned)
-  : d_buf(nullptr), d_len(length), d_rp(0), d_wp(0), d_pinned(false)
+  : ring_(nullptr), capacity_(length), mask_((uint64_t)length - 1), pinned_(false),
+    committed_(0), discarded_(0), sleepers_(0)
 {
 	if (pinned) {
 		void *p = nullptr;
 		if (hipHostMalloc(&p, sizeof(std::complex<float>) * (size_t)length, hipHostMallocDefault) == hipSuccess) {
-			d_buf = (std::complex<float> *)p;
-			d_pinned = true;
+			ring_ = (std::complex<float> *)p;
+			pinned_ = true;
 		}
 	}
-	if (!d_buf)
-		d_buf = new std::complex<float>[length];
+	if (!ring_)
+		ring_ = new std::complex<float>[length];
 }
 
 fifo::~fifo()
 {
-	if (d_pinned)
-		(void)hipHostFree(d_buf);
+	if (pinned_)
+		(void)hipHostFree(ring_);
 	else
-		delete[] d_buf;
+		delete[] ring_;
 }
 
-int fifo::used() { return (d_wp - d_rp) & (d_len - 1); }		/* fifo.cc:34-38 */
-int fifo::free() { return (d_len - 1) - used(); }			/* fifo.cc:28-32: one slot stays empty */
-int fifo::write_max_size() { return d_len - d_wp; }			/* fifo.cc:40-44 */
-int fifo::read_max_size() { return d_len - d_rp; }			/* fifo.cc:70-74 */
-
-std::complex<float> *fifo::write_prepare(int size, bool wait)		/* fifo.cc:46-58 */
+template <class Pred>
+bool fifo::sleep_until(Pred ready, int timeout_ms)
 {
-	std::unique_lock<std::mutex> lock(d_mutex);
-	if (!wait && free() < size)
+	if (ready())
+		return true;
+	std::unique_lock<std::mutex> lk(sleep_mutex_);
+	sleepers_.fetch_add(1, std::memory_order_seq_cst);
+	bool ok;
+	if (timeout_ms < 0) {
+		sleep_cv_.wait(lk, ready);
+		ok = true;
+	} else {
+		ok = sleep_cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready);
+	}
+	sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+	return ok;
+}
+
+void fifo::wake()
+{
+	if (sleepers_.load(std::memory_order_seq_cst) == 0)
+		return;
+	{ std::lock_guard<std::mutex> lk(sleep_mutex_); }	/* the sleeper is either before its re-check or inside wait() */
+	sleep_cv_.notify_all();
+}
+
+std::complex<float> *fifo::write_prepare(int size, bool wait)
+{
+	if (!sleep_until([&] { return free() >= size; }, wait ? -1 : 0))
 		return nullptr;
-	while (free() < size)
-		d_cond_full.wait(lock);
-	return &d_buf[d_wp];
+	return ring_ + (committed_.load(std::memory_order_relaxed) & mask_);
 }
 
-void fifo::write_commit(int size)					/* fifo.cc:60-68 */
+std::complex<float> *fifo::write_prepare_for(int size, int timeout_ms)
 {
-	std::unique_lock<std::mutex> lock(d_mutex);
-	d_wp = (d_wp + size) & (d_len - 1);
-	d_cond_empty.notify_one();
-}
-
-std::complex<float> *fifo::read_peek(int size, bool wait)		/* fifo.cc:76-88 */
-{
-	std::unique_lock<std::mutex> lock(d_mutex);
-	if (!wait && used() < size)
+	if (!sleep_until([&] { return free() >= size; }, timeout_ms))
 		return nullptr;
-	while (used() < size)
-		d_cond_empty.wait(lock);
-	return &d_buf[d_rp];
+	return ring_ + (committed_.load(std::memory_order_relaxed) & mask_);
 }
 
-void fifo::read_discard(int size)					/* fifo.cc:90-98 */
+void fifo::write_commit(int size)
 {
-	std::unique_lock<std::mutex> lock(d_mutex);
-	d_rp = (d_rp + size) & (d_len - 1);
-	d_cond_full.notify_one();
+	committed_.fetch_add((uint64_t)size, std::memory_order_seq_cst);	/* publishes the samples written before it */
+	wake();
 }
 
-int fifo::peek_max_size_at(int offset)
+std::complex<float> *fifo::read_peek(int size, bool wait)
 {
-	std::unique_lock<std::mutex> lock(d_mutex);
-	const int avail = used() - offset;
-	const int to_end = d_len - ((d_rp + offset) & (d_len - 1));
+	if (!sleep_until([&] { return used() >= size; }, wait ? -1 : 0))
+		return nullptr;
+	return ring_ + (discarded_.load(std::memory_order_relaxed) & mask_);
+}
+
+void fifo::read_discard(int size)
+{
+	discarded_.fetch_add((uint64_t)size, std::memory_order_seq_cst);
+	wake();
+}
+
+int fifo::peek_max_size_at(int offset) const
+{
+	const uint64_t at = discarded_.load(std::memory_order_relaxed) + (uint64_t)offset;
+	const int64_t avail = (int64_t)(committed_.load(std::memory_order_acquire) - at);
+	const int64_t to_end = (int64_t)capacity_ - (int64_t)(at & mask_);
 	if (avail <= 0)
 		return 0;
-	return avail < to_end ? avail : to_end;
+	return (int)(avail < to_end ? avail : to_end);
 }
 
-std::complex<float> *fifo::peek_at(int offset)
+std::complex<float> *fifo::peek_at(int offset) const
 {
-	std::unique_lock<std::mutex> lock(d_mutex);
-	return &d_buf[(d_rp + offset) & (d_len - 1)];
+	return ring_ + ((discarded_.load(std::memory_order_relaxed) + (uint64_t)offset) & mask_);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -105,7 +129,7 @@ const int sink_runtime::k_db_per_div[5] = {1, 2, 5, 10, 20};		/* base_sink_c_imp
 sink_runtime::sink_runtime(int fifo_length)
   : d_fosphor(nullptr), d_width(1024), d_height(1024), d_freq_cb(nullptr), d_freq_user(nullptr),
     d_active(false), d_frozen(false), d_visible(true), d_draining(false),
-    d_settings_changed(0), d_db_ref(0), d_db_per_div_idx(3),
+    d_pending(0), d_db_ref(0), d_db_per_div_idx(3),
     d_zoom_enabled(false), d_zoom_center(0.5), d_zoom_width(0.2), d_ratio(0.35f),
     d_have_window(false), d_frames(0), d_samples(0),
     d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0),
@@ -186,18 +210,49 @@ void sink_runtime::retire_uploads(bool wait_all)
 	}
 }
 
-void sink_runtime::settings_mark_changed(uint32_t s)			/* :204-209 */
+/* The pane layout of base_sink_c_impl.cc:257-289 as data: what each pane gets is decided first (a plain value), then
+ * written into the two fosphor_render structs under the render lock and refreshed. */
+namespace {
+struct pane { int pos_x, width; };
+struct split { pane main, zoom; int main_set, main_clear; };
+
+/* zoom on: the main pane takes 65 % of the window and shows the zoom channel instead of the colour scale; the zoom
+ * pane starts 10 px inside it and takes the rest.  zoom off: one pane, full width, colour scale back. */
+split split_window(int width, bool zoom)
 {
-	std::lock_guard<std::mutex> lock(d_settings_mutex);
-	d_settings_changed |= s;
+	split sp;
+	const int cut = zoom ? (int)(width * 0.65f) : width;
+	sp.main = pane{ 0, cut };
+	sp.zoom = pane{ cut - 10, width - cut + 10 };
+	sp.main_set   = zoom ? FRO_CHANNELS : FRO_COLOR_SCALE;
+	sp.main_clear = zoom ? FRO_COLOR_SCALE : FRO_CHANNELS;
+	return sp;
+}
 }
 
-uint32_t sink_runtime::settings_get_and_reset_changed()			/* :211-218 */
+void sink_runtime::layout_panes()
 {
-	std::lock_guard<std::mutex> lock(d_settings_mutex);
-	uint32_t v = d_settings_changed;
-	d_settings_changed = 0;
-	return v;
+	const split sp = split_window(d_width, d_zoom_enabled);
+	std::lock_guard<std::mutex> lk(d_render_mutex);
+	struct fosphor_render *both[2] = { d_render_main, d_render_zoom };
+
+	d_render_main->width = sp.main.width;
+	d_render_main->options = (d_render_main->options | sp.main_set) & ~sp.main_clear;
+	if (d_zoom_enabled) {				/* the zoom pane keeps its last geometry while it is hidden */
+		d_render_zoom->pos_x = sp.zoom.pos_x;
+		d_render_zoom->width = sp.zoom.width;
+	}
+	struct fosphor_channel &ch = d_render_main->channels[0];
+	ch.enabled = d_zoom_enabled;
+	ch.center  = (float)d_zoom_center;
+	ch.width   = (float)d_zoom_width;
+	d_render_zoom->freq_center = ch.center;
+	d_render_zoom->freq_span   = ch.width;
+	for (struct fosphor_render *r : both) {
+		r->height = d_height;
+		r->histo_wf_ratio = d_ratio;
+		fosphor_render_refresh(r);
+	}
 }
 
 void sink_runtime::settings_apply(uint32_t s)				/* :220-288, compute-relevant part */
@@ -208,31 +263,14 @@ void sink_runtime::settings_apply(uint32_t s)				/* :220-288, compute-relevant p
 		fosphor_set_frequency_range(d_fosphor, d_frequency.center, d_frequency.span);
 	if ((s & SETTING_FFT_WINDOW) && d_have_window)
 		fosphor_set_fft_window(d_fosphor, d_fft_window);
-	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS)) {		/* :257-289 */
-		if (d_zoom_enabled) {
-			int a = (int)(d_width * 0.65f);
-			d_render_main->width = a;
-			d_render_main->options |= FRO_CHANNELS;
-			d_render_main->options &= ~FRO_COLOR_SCALE;
-			d_render_zoom->pos_x = a - 10;
-			d_render_zoom->width = d_width - a + 10;
-		} else {
-			d_render_main->width = d_width;
-			d_render_main->options &= ~FRO_CHANNELS;
-			d_render_main->options |= FRO_COLOR_SCALE;
-		}
-		d_render_main->height = d_height;
-		d_render_zoom->height = d_height;
-		d_render_main->histo_wf_ratio = d_ratio;
-		d_render_zoom->histo_wf_ratio = d_ratio;
-		d_render_main->channels[0].enabled = d_zoom_enabled;
-		d_render_main->channels[0].center = (float)d_zoom_center;
-		d_render_main->channels[0].width = (float)d_zoom_width;
-		d_render_zoom->freq_center = (float)d_zoom_center;
-		d_render_zoom->freq_span = (float)d_zoom_width;
-		fosphor_render_refresh(d_render_main);
-		fosphor_render_refresh(d_render_zoom);
-	}
+	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS))
+		layout_panes();
+}
+
+struct fosphor_render sink_runtime::render_copy(bool zoom) const
+{
+	std::lock_guard<std::mutex> lk(d_render_mutex);
+	return zoom ? *d_render_zoom : *d_render_main;
 }
 
 void sink_runtime::reshape(int width, int height)			/* :291-296 */
@@ -244,6 +282,7 @@ void sink_runtime::reshape(int width, int height)			/* :291-296 */
 
 bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, double *freq)	/* :371-397 */
 {
+	std::lock_guard<std::mutex> lk(d_render_mutex);	/* the worker re-lays the panes and owns d_fosphor's lifetime */
 	if (action != CLICK || !d_fosphor)
 		return false;
 	const int in_main = fosphor_render_pos_inside(d_render_main, x, y);
@@ -264,7 +303,11 @@ bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, dou
 
 void sink_runtime::worker()						/* :77-122 */
 {
-	d_fosphor = fosphor_init();
+	{
+		struct fosphor *f = fosphor_init();
+		std::lock_guard<std::mutex> lk(d_render_mutex);
+		d_fosphor = f;
+	}
 	if (!d_fosphor) {
 		d_active = false;
 		return;
@@ -274,8 +317,11 @@ void sink_runtime::worker()						/* :77-122 */
 		render();
 	(void)fosphor_amd_finish(d_fosphor);
 	retire_uploads(true);
-	fosphor_release(d_fosphor);
-	d_fosphor = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(d_render_mutex);	/* no click is being mapped through it */
+		fosphor_release(d_fosphor);
+		d_fosphor = nullptr;
+	}
 }
 
 void sink_runtime::render()						/* :130-201 */
@@ -350,9 +396,14 @@ int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432
 		l = mw;
 	if (!l)
 		return 0;
-	std::complex<float> *dst = d_fifo->write_prepare(l, true);
-	if (!dst)
-		return 0;
+	/* blocks while the FIFO is full -- as long as somebody is consuming: a sink that is not running (never started,
+	 * stopped, core failed to initialise) returns 0 instead of blocking for ever */
+	std::complex<float> *dst = nullptr;
+	while (!dst) {
+		if (!d_active)
+			return 0;
+		dst = d_fifo->write_prepare_for(l, 100);
+	}
 	if (l >= 128 * 1024) {
 		/* one core copies ~12 GB/s; the link behind the FIFO carries 4-5 times that */
 		const size_t part = ((size_t)l / (kCopyHelpers + 1)) & ~(size_t)1023;
@@ -486,18 +537,34 @@ double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, in
 	/* the sink consumes whole 16-spectrum groups: a remainder stays in the FIFO until more samples arrive */
 	const uint64_t want = before + (((uint64_t)n * (uint64_t)repeats) & ~(uint64_t)(16 * 1024 - 1));
 	auto t0 = std::chrono::steady_clock::now();
+	/* "no progress for 30 s" at any point -- while feeding (the sink is not running, or frozen with a full FIFO) or
+	 * while waiting for the tail -- gives up */
+	auto t_progress = t0;
+	uint64_t seen = before;
+	auto stalled = [&]() {
+		const uint64_t now_done = s->s.samples_processed();
+		const auto now = std::chrono::steady_clock::now();
+		if (now_done != seen) { seen = now_done; t_progress = now; }
+		return std::chrono::duration<double>(now - t_progress).count() > 30.0;
+	};
 	for (int r = 0; r < repeats; r++) {
 		int pos = 0;
 		while (pos < n) {
 			int l = n - pos < chunk ? n - pos : chunk;
 			int took = s->s.work(l, in + pos);
 			pos += took;
+			if (took) {
+				t_progress = std::chrono::steady_clock::now();
+			} else {
+				if (stalled())
+					return -1.0;
+				std::this_thread::sleep_for(std::chrono::microseconds(200));
+			}
 		}
 	}
-	auto t_fed = std::chrono::steady_clock::now();
 	while (s->s.samples_processed() < want) {
 		std::this_thread::sleep_for(std::chrono::microseconds(50));
-		if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fed).count() > 30.0)
+		if (stalled())
 			return -1.0;			/* the worker is not consuming (stopped, frozen, device error) */
 	}
 	return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -517,7 +584,7 @@ int   fosphor_amd_sink_mouse_action(fosphor_amd_sink *s, int action, int x, int 
 }
 void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_render *out)
 {
-	*out = zoom ? *s->s.render_zoom() : *s->s.render_main();
+	*out = s->s.render_copy(zoom != 0);
 }
 void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double c, double sp) { s->s.set_frequency_range(c, sp); }
 void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win) { s->s.set_fft_window(win); }

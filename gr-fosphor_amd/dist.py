@@ -240,6 +240,27 @@ class ShardedFosphor:
         self.f.close()
 
 
+def agree_on_transport(build_native, build_fallback, world, all_reduce_min, log=None):
+    """Every rank must exchange through the same transport.  Each rank tries build_native() (the library's own RCCL
+    communicator); the ranks agree with one MIN all-reduce of "it worked here"; unless it worked everywhere, every rank --
+    including those whose native set-up succeeded, which is closed again -- builds build_fallback() instead.
+    all_reduce_min(int) -> int is the caller's collective (torch.distributed on any backend).  Nothing here touches a GPU or
+    re-executes anything: it can run before or after the first HIP call.  Returns (object, "native" | "fallback")."""
+    try:
+        obj, ok = build_native(), 1
+    except Exception as e:
+        if log:
+            log("native exchange unavailable on this rank (%s)" % e)
+        obj, ok = None, 0
+    if world > 1:
+        ok = int(all_reduce_min(ok))
+    if ok:
+        return obj, "native"
+    if obj is not None:
+        obj.close()
+    return build_fallback(), "fallback"
+
+
 def combine_partials_numpy(parts):
     """Reference combination rule on host arrays: [(hc, live, max), ...] -> (hc, live, max)."""
     hc = np.sum([p[0].astype(np.uint64) for p in parts], axis=0).astype(np.uint32)

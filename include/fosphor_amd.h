@@ -98,6 +98,9 @@ struct fosphor_amd_buffers
 	float     histo_scale, histo_offset;	/* cl.c:1087-1088 */
 };
 int fosphor_amd_get_buffers(struct fosphor *self, struct fosphor_amd_buffers *out);
+/* The same without the hit-count view: d_hitcount is NULL, no kernel is launched and nothing is waited for (for
+ * front ends that poll waterfall_pos / the pointers per frame). */
+int fosphor_amd_get_buffers_nohc(struct fosphor *self, struct fosphor_amd_buffers *out);
 
 /* Host copies (synchronise first).  which: 0 waterfall, 1 histogram, 2 spectrum,
  * 3 hitcount.  `bytes` must equal the buffer size.  0 / -EINVAL / -EIO. */

@@ -35,39 +35,52 @@
 
 namespace fosphor_amd {
 
-/* lib/fifo.h:20-46 -- same interface and semantics: power-of-two ring of complex samples, one
- * slot kept empty (free = len - 1 - used, fifo.cc:28-38), contiguous zero-copy regions
- * (write_max_size / read_max_size = distance to the end of the ring), blocking prepare/peek. */
+/* lib/fifo.h:20-46 -- the same interface and observable semantics: power-of-two ring of complex samples, one
+ * slot kept empty (free = len - 1 - used, fifo.cc:28-38), contiguous zero-copy regions (write_max_size /
+ * read_max_size = distance to the end of the ring), blocking prepare / peek.
+ * Built differently: a single-producer / single-consumer ring on two monotonic 64-bit counters (samples ever
+ * committed, samples ever discarded; position = counter & mask).  used() / free() and the two commit paths are
+ * lock-free atomic operations; the mutex and the condition variable exist only to put a blocked side to sleep. */
 class fifo
 {
  public:
 	explicit fifo(int length, bool pinned = false);
 	~fifo();
+	fifo(const fifo &) = delete;
+	fifo &operator=(const fifo &) = delete;
 
-	int free();
-	int used();
+	int free() const { return capacity_ - 1 - used(); }
+	int used() const { return (int)(committed_.load(std::memory_order_seq_cst) - discarded_.load(std::memory_order_seq_cst)); }
 
-	int write_max_size();
+	int write_max_size() const { return capacity_ - (int)(committed_.load(std::memory_order_relaxed) & mask_); }
 	std::complex<float> *write_prepare(int size, bool wait = true);
+	/* write_prepare that gives up: NULL when `size` free slots did not appear within timeout_ms */
+	std::complex<float> *write_prepare_for(int size, int timeout_ms);
 	void write_commit(int size);
 
-	int read_max_size();
+	int read_max_size() const { return capacity_ - (int)(discarded_.load(std::memory_order_relaxed) & mask_); }
 	std::complex<float> *read_peek(int size, bool wait = true);
 	void read_discard(int size);
-	/* regions beyond the read pointer (the sink keeps several uploads in flight before discarding):
-	 * contiguous samples available at `offset` behind the read pointer, and their address */
-	int peek_max_size_at(int offset);
-	std::complex<float> *peek_at(int offset);
-	int length() const { return d_len; }
+	/* regions beyond the read position (the sink keeps several uploads in flight before discarding):
+	 * contiguous samples available at `offset` behind the read position, and their address */
+	int peek_max_size_at(int offset) const;
+	std::complex<float> *peek_at(int offset) const;
+	int length() const { return capacity_; }
 
-	bool pinned() const { return d_pinned; }
+	bool pinned() const { return pinned_; }
 
  private:
-	std::complex<float> *d_buf;
-	int d_len, d_rp, d_wp;
-	bool d_pinned;
-	std::mutex d_mutex;
-	std::condition_variable d_cond_empty, d_cond_full;
+	template <class Pred> bool sleep_until(Pred ready, int timeout_ms);
+	void wake();
+
+	std::complex<float> *ring_;
+	int capacity_;
+	uint64_t mask_;
+	bool pinned_;
+	std::atomic<uint64_t> committed_, discarded_;	/* totals since construction */
+	std::atomic<int> sleepers_;
+	std::mutex sleep_mutex_;
+	std::condition_variable sleep_cv_;
 };
 
 /* include/gnuradio/fosphor/base_sink_c.h:24-59 + lib/base_sink_c_impl.{h,cc}, data path only */
@@ -99,8 +112,8 @@ class sink_runtime
 	bool execute_mouse_action(mouse_action_t action, int x, int y, double *freq = nullptr);
 	void set_freq_callback(void (*cb)(double freq, void *user), void *user) { d_freq_cb = cb; d_freq_user = user; }
 	void reshape(int width, int height);			/* cb_reshape, :291-296 */
-	const struct fosphor_render *render_main() const { return d_render_main; }
-	const struct fosphor_render *render_zoom() const { return d_render_zoom; }
+	/* copy of a pane layout as the worker last computed it (zoom = false: main pane) */
+	struct fosphor_render render_copy(bool zoom) const;
 	void set_frequency_range(double center, double span);	/* :399-405 */
 	void set_frequency_center(double center);
 	void set_frequency_span(double span);
@@ -125,9 +138,10 @@ class sink_runtime
 	void render();
 	void retire_uploads(bool wait_all);
 	void copy_helper(int idx);
-	void settings_mark_changed(uint32_t s);
-	uint32_t settings_get_and_reset_changed();
+	void settings_mark_changed(uint32_t s) { d_pending.fetch_or(s, std::memory_order_acq_rel); }		/* base_sink_c_impl.cc:204-209 */
+	uint32_t settings_get_and_reset_changed() { return d_pending.exchange(0, std::memory_order_acq_rel); }	/* :211-218 */
 	void settings_apply(uint32_t s);
+	void layout_panes();
 
 	fifo *d_fifo;
 	struct fosphor *d_fosphor;
@@ -137,8 +151,8 @@ class sink_runtime
 	void *d_freq_user;
 	std::thread d_worker;
 	std::atomic<bool> d_active, d_frozen, d_visible, d_draining;
-	std::mutex d_settings_mutex;
-	uint32_t d_settings_changed;
+	std::atomic<uint32_t> d_pending;		/* SETTING_* bits waiting for the worker */
+	mutable std::mutex d_render_mutex;		/* the two pane layouts + d_fosphor: worker vs. UI thread (the reference's d_render_mutex) */
 	int d_db_ref, d_db_per_div_idx;
 	bool d_zoom_enabled; double d_zoom_center, d_zoom_width; float d_ratio;
 	struct { double center, span; } d_frequency;
@@ -193,11 +207,13 @@ fosphor_amd_sink *fosphor_amd_sink_new(void);
 fosphor_amd_sink *fosphor_amd_sink_new_len(int fifo_length);
 /* Measurement: feeds `samples` (n complex samples) `repeats` times through work() from the calling thread, in
  * calls of `chunk` samples, waits until every whole 16-spectrum group of it has been processed, and returns the seconds
- * it took (-1.0 if the worker stopped consuming for 30 s).  work() is single-producer, like the GR scheduler's calls. */
+ * it took (-1.0 if nothing was consumed for 30 s at any point: sink not started, frozen, or device error).  work() is single-producer, like the GR scheduler's calls. */
 double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, int chunk, int repeats);
 void  fosphor_amd_sink_free(fosphor_amd_sink *s);
 int   fosphor_amd_sink_start(fosphor_amd_sink *s);
 int   fosphor_amd_sink_stop(fosphor_amd_sink *s);
+/* work(): copies up to n samples into the FIFO and returns how many it took; blocks while the FIFO is full and the
+ * worker is consuming, returns 0 when the sink is not running (not started, stopped, or its core failed to initialise). */
 int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n);
 void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action);
 /* cb_reshape (window size in pixels) and execute_mouse_action(CLICK, x, y) of base_sink_c_impl.cc:291-296,371-397:

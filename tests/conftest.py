@@ -21,3 +21,12 @@ def oracle_built():
     from oracle_lib import build_oracle
     build_oracle(ref=False)
     return True
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How many histogram cells assert_hist_close excused near the 0.01 fast-exit level (display.cl:237-238)."""
+    mod = sys.modules.get("test_gpu_parity")
+    ex = getattr(mod, "EXCUSED", None) if mod else None
+    if ex is not None:
+        terminalreporter.write_line("fast-exit-excused histogram cells this session: %d%s"
+                                    % (ex["cells"], (" (" + "; ".join(ex["where"][:8]) + ")") if ex["where"] else ""))

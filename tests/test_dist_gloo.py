@@ -90,3 +90,75 @@ def test_allreduce_partials_world2_gloo(oracle_built, tmp_path):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
         assert "rank %d ok" % r in out
+
+
+TRANSPORT_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["FOSPHOR_ROOT"])
+import torch, torch.distributed as dist
+from _pkg import gr_fosphor_amd
+from gr_fosphor_amd.dist import agree_on_transport, shard_range
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+fail_on = int(os.environ["FAIL_ON"])          # rank whose native set-up fails (-1: none)
+
+class Obj:
+    def __init__(self, kind): self.kind, self.closed = kind, False
+    def close(self): self.closed = True
+
+made = []
+def native():
+    if rank == fail_on:
+        raise RuntimeError("fosphor_amd_comm_init -> -38")     # what NativeComm raises without an RCCL library
+    o = Obj("native"); made.append(o); return o
+def fallback():
+    o = Obj("torch"); made.append(o); return o
+def all_reduce_min(v):
+    t = torch.tensor([v], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+logs = []
+obj, which = agree_on_transport(native, fallback, world, all_reduce_min, log=logs.append)
+want = "native" if fail_on < 0 else "fallback"
+assert which == want, (rank, which)
+assert obj.kind == ("native" if fail_on < 0 else "torch")
+if fail_on >= 0 and rank != fail_on:
+    # this rank's native object was built, then closed again when the ranks agreed to fall back together
+    assert [o.kind for o in made] == ["native", "torch"] and made[0].closed and not made[1].closed
+if rank == fail_on:
+    assert logs and "unavailable" in logs[0]
+# every rank ended on the same transport
+kinds = [None] * world
+dist.all_gather_object(kinds, obj.kind)
+assert len(set(kinds)) == 1, kinds
+# the time split bench.py's frame mode uses at every N the driver runs
+for w in (1, 2, 4, 8):
+    spans = [shard_range(8192, r, w) for r in range(w)]
+    assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+    assert spans[-1][0] + spans[-1][1] == 8192 and all(n % 16 == 0 for _, n in spans)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+@pytest.mark.parametrize("fail_on", [-1, 0, 1])
+def test_transport_agreement_world2_gloo(tmp_path, fail_on):
+    """bench.py --gpus N / ShardedFosphor: if the library's own RCCL communicator cannot be set up on ANY rank, EVERY rank
+    falls back to the torch transport (and a rank whose set-up had succeeded closes it again)."""
+    script = tmp_path / "worker.py"
+    script.write_text(TRANSPORT_WORKER)
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29631 + fail_on),
+               WORLD_SIZE="2", OMP_NUM_THREADS="1", FAIL_ON=str(fail_on))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+        assert "rank %d ok" % r in out

@@ -62,6 +62,11 @@ def assert_close(a, b, what, rtol=RTOL, atol=ATOL):
         raise AssertionError("%s: %d / %d outside tolerance; first: %s" % (what, (~ok).sum(), ok.size, msg))
 
 
+# cells assert_hist_close let through because they sit at the fast-exit level: reported at the end of the session
+# (tests/conftest.py prints it), so that a regression that starts leaning on the excuse is visible
+EXCUSED = {"cells": 0, "where": []}
+
+
 def assert_hist_close(h_gpu, h_ref, what):
     """Persistence histogram.  Cells the fast-exit rule (display.cl:237-238, hv <= 0.01 and no
     hits -> not rewritten) treats differently because the two float states straddle 0.01 by
@@ -73,6 +78,10 @@ def assert_hist_close(h_gpu, h_ref, what):
         hard = bad & ~near_exit
         assert not hard.any(), "%s: %d cells differ (max %g)" % (what, hard.sum(), d[hard].max())
         assert bad.sum() <= max(2, bad.size // 20000), "%s: %d cells straddle the 0.01 fast-exit" % (what, bad.sum())
+        EXCUSED["cells"] += int(bad.sum())
+        EXCUSED["where"].append("%s: %d" % (what, int(bad.sum())))
+        print("[assert_hist_close] %s: %d of %d cells excused (reference value within 2e-4 of the 0.01 fast-exit level); "
+              "%d excused so far in this session" % (what, int(bad.sum()), bad.size, EXCUSED["cells"]))
 
 
 def compare_state(f, o, what, wf_rows=None):
@@ -270,18 +279,14 @@ def test_multi_batch_launch_equals_sequential_calls(amd, torch_cuda, oracle_buil
 
 
 @pytest.mark.parametrize("env", [{"FOSPHOR_AMD_PIPE3": "1"}, {"FOSPHOR_AMD_OVERLAP": "0"}, {"FOSPHOR_AMD_K1": "2"},
-                                 {"FOSPHOR_AMD_K1": "5"}, {"FOSPHOR_AMD_K1": "6"}, {"FOSPHOR_AMD_K1": "7"}, {"FOSPHOR_AMD_K23": "1"},
                                  {"FOSPHOR_AMD_ALT": "0"}, {"FOSPHOR_AMD_TILE": "16"}, {"FOSPHOR_AMD_SUB_LOG2": "17"},
-                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"}, {"FOSPHOR_AMD_SUB_LOG2": "18", "FOSPHOR_AMD_K23": "1"},
-                                 {"FOSPHOR_AMD_ROWMASK": "1"}, {"FOSPHOR_AMD_ROWMASK": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"},
-                                 {"FOSPHOR_AMD_WAVEBITS": "1"}, {"FOSPHOR_AMD_WAVEBITS": "1", "FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"}])
+                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "_relaxed": "1"},
+                                 {"FOSPHOR_AMD_SUB_LOG2": "17", "FOSPHOR_AMD_PIPE3": "1"}])
 def test_pipeline_options_do_not_change_results(amd, torch_cuda, oracle_built, monkeypatch, env):
-    """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the K1 variants
-    (two waves per spectrum; asm-prefetched, one or two spectra ahead; three waves per SIMD with the IQ landing in the
-    exchange slab by LDS-DMA), the fused count+merge kernel, the sparse count hand-off (row masks + hot-row flags), the tile
-    length, sub-launches of one batch on alternating FFT streams (with and without stream ordering against the
-    caller) are scheduling choices: several back-to-back launches, then a switch to the sharded path and back,
-    must leave exactly the state of the sequential reference calls."""
+    """The third stream (K3 beside the next K2, second hit-count set), the single-stream mode, the two-waves-per-spectrum
+    FFT kernel (the one odd overlap hops use), the tile length, sub-launches of one batch on alternating FFT streams (with and
+    without stream ordering against the caller) are scheduling choices: several back-to-back launches, then a switch to the
+    sharded path and back, must leave exactly the state of the sequential reference calls."""
     torch = torch_cuda
     for k, v in env.items():
         if not k.startswith("_"):
@@ -479,6 +484,36 @@ def test_c3_full_batch_properties(amd, torch_cuda, oracle_built):
     f.close(); f2.close()
 
 
+def test_table_change_between_relaxed_calls(amd, torch_cuda, oracle_built, monkeypatch):
+    """Relaxed input ordering: the FFT kernels of a call may still be running on the second FFT stream when the next call
+    begins.  A window / power-range change between two such calls must not reach the earlier call's spectra (the tables are
+    re-uploaded only after every FFT stream has drained) and must apply to all of the later call's: the state equals the
+    oracle's after the same sequence."""
+    torch = torch_cuda
+    monkeypatch.setenv("FOSPHOR_AMD_SUB_LOG2", "17")		# 2 batches of 64 spectra per sub-launch: 4 sub-launches per call
+    nbat, b = 8, 64
+    f = amd.Fosphor(max_spectra=nbat * b)
+    assert f.set_input_ordering(False) == 0
+    o = Oracle()
+    rng = np.random.default_rng(5)
+    keep = []
+    for call in range(4):
+        x = add_tone(gaussian_iq(nbat * b * 1024, 700 + call), 0.1, 0.07 * (call + 1))
+        keep.append(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        if call in (1, 3):
+            win = (0.5 + rng.random(1024)).astype(np.float32)		# a window that visibly changes every bin
+            f.set_fft_window(win); o.set_window(win)
+        if call == 2:
+            f.set_power_range(-10, 5); o.set_power_range(-10, 5)
+        assert f.process_device(keep[-1], nbat, b) == 0			# no synchronisation between the calls
+        for k in range(nbat):
+            assert o.process(x[k * b * 1024:(k + 1) * b * 1024], nthreads=8) == 0
+    assert f.finish() >= 0
+    compare_state(f, o, "tables changed between relaxed calls")
+    f.close()
+
+
 def test_full_size_properties(amd, torch_cuda):
     """BASELINE config C2 size (batch 1024, 256 bins), 4 batches per launch: size-independent
     properties -- counts sum to the batch per column, determinism, and hit-count additivity
@@ -549,46 +584,84 @@ def test_sharded_batch_equals_single_launch(amd, torch_cuda, oracle_built):
         fr.close()
 
 
-@pytest.mark.parametrize("no_sum16", ["", "1"])
-def test_sharded_frame_many_chunks(amd, torch_cuda, oracle_built, monkeypatch, no_sum16):
-    """A time shard of several 1024-spectrum chunks (what a display frame is on every rank): two 'ranks'
-    take 4096 spectra each of one 8192-spectrum batch.  The shard's hit counts go through per-chunk
-    packed 16-bit slabs + k2c_sum (default) or through 32-bit global atomics (FOSPHOR_AMD_NO_SUM16=1);
-    both must give the oracle's counts for the whole batch."""
+@pytest.mark.parametrize("world,no_sum16,sliced", [(2, "", False), (2, "1", False), (4, "", False), (8, "", False),
+                                                   (4, "", True), (8, "", True)])
+def test_sharded_frame_many_chunks(amd, torch_cuda, oracle_built, monkeypatch, world, no_sum16, sliced):
+    """BASELINE C4 in emulation: `world` instances on this one GPU take total / world spectra each of one
+    8192-spectrum batch through dist.shard_range (world 8: 1024 per rank, the configuration's own split).  A shard of
+    several 1024-spectrum chunks leaves per-chunk packed 16-bit slabs + k2c_sum (default) or 32-bit global atomics
+    (FOSPHOR_AMD_NO_SUM16=1).  torch adds stand in for the collective: all-reduce + full merge, or (sliced) what
+    reduce-scatter leaves -- rank r holds the summed counts only in cells [r C / world, (r + 1) C / world) -- followed by
+    fosphor_amd_merge_sliced and an emulated all-gather of the histogram slices.  Every rank must end with the oracle's state
+    for the whole batch."""
     torch = torch_cuda
+    from gr_fosphor_amd.dist import shard_range, wrap_device_array
     if no_sum16:
         monkeypatch.setenv("FOSPHOR_AMD_NO_SUM16", "1")
     else:
         monkeypatch.delenv("FOSPHOR_AMD_NO_SUM16", raising=False)
-    total = 8192
+    total, nb = 8192, 256
     x = add_tone(gaussian_iq(total * 1024, 53), 0.04, -0.12)
     d = torch.from_numpy(x).cuda()
-    ranks = [amd.Fosphor(max_spectra=total // 2, n_bins=256) for _ in range(2)]
+    ranks = [amd.Fosphor(max_spectra=total // world, n_bins=nb) for _ in range(world)]
     parts = []
     for r, fr in enumerate(ranks):
-        off = r * (total // 2)
-        assert fr.accumulate_device(d[off * 1024:(off + total // 2) * 1024], total // 2, off, total) == 0
+        off, n = shard_range(total, r, world)
+        assert (off, n) == (r * (total // world), total // world)
+        assert fr.accumulate_device(d[off * 1024:(off + n) * 1024], n, off, total) == 0
         fr.finish()
         parts.append(fr.partials())
-    from gr_fosphor_amd.dist import wrap_device_array
     hc = [wrap_device_array(p.d_hc, (p.n_hc,), torch.int32) for p in parts]
     ls = [wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32) for p in parts]
     mx = [wrap_device_array(p.d_max, (p.n_cols,), torch.float32) for p in parts]
-    hc_sum, ls_sum, mx_max = hc[0] + hc[1], ls[0] + ls[1], torch.maximum(mx[0], mx[1])
-    for r in range(2):
-        hc[r].copy_(hc_sum); ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
+    hc_sum = torch.stack(hc).sum(0, dtype=torch.int32)
+    ls_sum = torch.stack(ls).sum(0)
+    mx_max = torch.stack(mx).max(0).values
+    cells = nb * 1024
+    per = cells // world
+    for r in range(world):
+        if sliced:
+            # a reduce-scatter leaves the sums in the rank's own slice only; poison the rest so that a merge reading
+            # outside its slice cannot pass
+            hc[r].fill_(0x5a5a5a5)
+            hc[r][r * per:(r + 1) * per].copy_(hc_sum[r * per:(r + 1) * per])
+        else:
+            hc[r].copy_(hc_sum)
+        ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
     torch.cuda.synchronize()
-    for fr in ranks:
-        assert fr.merge(total) == 0
-    o = Oracle(n_bins=256)
+    o = Oracle(n_bins=nb)
     assert o.process(x, strict=False, nthreads=8) == 0
-    for fr in ranks:
-        assert np.array_equal(fr.hitcount, o.hitcount.T)
-        assert int(fr.hitcount.sum()) == total * 1024
-        assert_hist_close(fr.histogram, o.histogram, "frame histogram")
-        assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "frame live")
-        assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "frame max-hold")
-    assert_close(ranks[1].waterfall, o.waterfall, "frame waterfall (rank 1 rows)")
+    if sliced:
+        for r, fr in enumerate(ranks):
+            assert fr.merge_sliced(total, world, r) == 0
+            assert fr.merge_sliced(total, 3, 0) == -errno.EINVAL		# cells % world != 0
+            assert fr.finish() >= 0
+        hists = [fr.histogram.reshape(-1) for fr in ranks]
+        full = np.concatenate([hists[r][r * per:(r + 1) * per] for r in range(world)]).reshape(nb, 1024)	# the all-gather
+        assert_hist_close(full, o.histogram, "frame histogram, world %d sliced" % world)
+        for r, fr in enumerate(ranks):
+            # outside its slice a rank's histogram is untouched (still the boot value 0)
+            own = np.zeros(cells, dtype=bool); own[r * per:(r + 1) * per] = True
+            assert not hists[r][~own].any(), "rank %d wrote outside its slice" % r
+            assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "frame live (sliced)")
+            assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "frame max-hold (sliced)")
+    else:
+        for fr in ranks:
+            assert fr.merge(total) == 0
+        for fr in ranks:
+            assert np.array_equal(fr.hitcount, o.hitcount.T)
+            assert int(fr.hitcount.sum()) == total * 1024
+            assert_hist_close(fr.histogram, o.histogram, "frame histogram, world %d" % world)
+            assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "frame live")
+            assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "frame max-hold")
+    # the ring holds the last 1024 spectra of the batch: with `world` ranks each owns the rows it computed
+    rows_per = total // world
+    for r, fr in enumerate(ranks):
+        lo = max(r * rows_per, total - 1024)
+        hi = (r + 1) * rows_per
+        if hi > lo:
+            sel = slice(lo - (total - 1024), hi - (total - 1024))
+            assert_close(fr.waterfall[sel], o.waterfall[sel], "frame waterfall (rank %d rows)" % r)
     for fr in ranks:
         fr.close()
 
@@ -1021,42 +1094,113 @@ def test_c5_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, fused
         amd.Fosphor(iq_fp16=True)
 
 
-def test_c5_sharded_two_ranks(amd, torch_cuda, oracle_built):
-    """C5 sharded: two ranks take 32 spectra each of one 64-spectrum frame (fp16 IQ); combined partials
-    give the oracle's counts for the whole frame on both ranks."""
+@pytest.mark.parametrize("world,sliced", [(2, False), (8, True)])
+def test_c5_sharded_two_ranks(amd, torch_cuda, oracle_built, world, sliced):
+    """C5 sharded (BASELINE configs[4] in emulation): `world` instances on this GPU take total / world spectra each of one
+    frame (fp16 IQ).  world 2: all-reduce + full merge on both.  world 8: what ShardedFosphor does for this 128 MiB state --
+    reduce-scatter (rank r keeps the summed counts of cells [r C / 8, (r + 1) C / 8) only), fosphor_amd_merge_sliced, and the
+    all-gather of the histogram slices -- with torch copies standing in for RCCL.  Combined state = the oracle's for the frame."""
     torch = torch_cuda
-    n, nb, rows, total = 65536, 512, 64, 64
+    from gr_fosphor_amd.dist import shard_range, wrap_device_array
+    n, nb, rows = 65536, 512, 64
+    total = 64 if world == 2 else 128
     x = add_tone(gaussian_iq(total * n, 95), 0.03, 0.2).astype(np.float16)
     d = torch.from_numpy(x).cuda()
-    ranks = [amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=32, iq_fp16=True) for _ in range(2)]
+    ranks = [amd.Fosphor(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=total // world, max_batches=2, iq_fp16=True)
+             for _ in range(world)]
     parts = []
     for r, fr in enumerate(ranks):
-        off = r * (total // 2)
-        assert fr.accumulate_device(d[off * n:(off + total // 2) * n], total // 2, off, total) == 0
+        off, cnt = shard_range(total, r, world)
+        assert fr.accumulate_device(d[off * n:(off + cnt) * n], cnt, off, total) == 0
         fr.finish()
         parts.append(fr.partials())
-    from gr_fosphor_amd.dist import wrap_device_array
     hc = [wrap_device_array(p.d_hc, (p.n_hc,), torch.int32) for p in parts]
     ls = [wrap_device_array(p.d_live_sum, (p.n_cols,), torch.float32) for p in parts]
     mx = [wrap_device_array(p.d_max, (p.n_cols,), torch.float32) for p in parts]
-    hc_sum, ls_sum, mx_max = hc[0] + hc[1], ls[0] + ls[1], torch.maximum(mx[0], mx[1])
-    for r in range(2):
-        hc[r].copy_(hc_sum); ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
+    hc_sum = torch.stack(hc).sum(0, dtype=torch.int32)
+    ls_sum = torch.stack(ls).sum(0)
+    mx_max = torch.stack(mx).max(0).values
+    cells = nb * n
+    per = cells // world
+    for r in range(world):
+        if sliced:
+            hc[r].fill_(0x5a5a5a5)
+            hc[r][r * per:(r + 1) * per].copy_(hc_sum[r * per:(r + 1) * per])
+        else:
+            hc[r].copy_(hc_sum)
+        ls[r].copy_(ls_sum); mx[r].copy_(mx_max)
     torch.cuda.synchronize()
-    for fr in ranks:
-        assert fr.merge(total) == 0
     o = Oracle(fft_len_log=16, n_bins=nb, wf_rows=rows)
     assert o.process(x.astype(np.float32), strict=False, nthreads=8) == 0
-    for fr in ranks:
-        assert np.array_equal(fr.hitcount, o.hitcount.T)
-        assert_hist_close(fr.histogram, o.histogram, "C5 sharded histogram")
-        assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "C5 sharded live")
-        assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "C5 sharded max-hold")
-    # rank 1 owns the last 32 spectra; rank 0's 32 rows were written at ring rows 0..31
-    assert_close(ranks[1].waterfall[32:64], o.waterfall[32:64], "C5 sharded waterfall (rank 1 rows)")
-    assert_close(ranks[0].waterfall[0:32], o.waterfall[0:32], "C5 sharded waterfall (rank 0 rows)")
+    if sliced:
+        for r, fr in enumerate(ranks):
+            assert fr.merge_sliced(total, world, r) == 0
+        hists = [fr.histogram.reshape(-1) for fr in ranks]
+        full = np.concatenate([hists[r][r * per:(r + 1) * per] for r in range(world)]).reshape(nb, n)
+        assert_hist_close(full, o.histogram, "C5 sharded histogram (8 slices)")
+        assert np.array_equal(hc_sum.cpu().numpy().view(np.uint32).reshape(nb, n), o.hitcount.T)
+        for fr in ranks:
+            assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "C5 sharded live")
+            assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "C5 sharded max-hold")
+    else:
+        for fr in ranks:
+            assert fr.merge(total) == 0
+        for fr in ranks:
+            assert np.array_equal(fr.hitcount, o.hitcount.T)
+            assert_hist_close(fr.histogram, o.histogram, "C5 sharded histogram")
+            assert_close(fr.spectrum[0, :, 1], o.spectrum[0, :, 1], "C5 sharded live")
+            assert_close(fr.spectrum[1, :, 1], o.spectrum[1, :, 1], "C5 sharded max-hold")
+    # a rank owns the ring rows of the spectra it computed among the last `rows` of the frame
+    per_rank = total // world
+    for r, fr in enumerate(ranks):
+        lo, hi = max(r * per_rank, total - rows), (r + 1) * per_rank
+        if hi > lo:
+            sel = [(t & (rows - 1)) for t in range(lo, hi)]
+            assert_close(fr.waterfall[sel], o.waterfall[sel], "C5 sharded waterfall (rank %d rows)" % r)
     for fr in ranks:
         fr.close()
+
+
+def test_c5_full_frame_properties(amd, torch_cuda, oracle_built):
+    """BASELINE C5 at the size bench.py --config C5 times: ONE frame of 1024 spectra x 65536 points (64 Mi samples of fp16
+    IQ, 512 bins) through the default (fused) FFT kernel and the sparse count hand-off.  The oracle cannot run 64 Mi samples
+    in seconds, so: size-independent properties (every column's counts sum to 1024; same input -> same bits), additivity
+    against two smaller launches, one of which -- the frame's first 16 spectra -- is checked against the oracle bit for bit,
+    and those 16 spectra's waterfall rows of the full frame against the oracle's."""
+    torch = torch_cuda
+    n, nb, rows, total = 65536, 512, 1024, 1024
+    g = torch.Generator(device="cuda"); g.manual_seed(97)
+    d = torch.empty((total * n, 2), dtype=torch.float32, device="cuda").normal_(0.0, 0.05, generator=g).to(torch.float16)
+    kw = dict(fft_len_log=16, n_bins=nb, wf_rows=rows, max_batches=2, iq_fp16=True)
+    f = amd.Fosphor(max_spectra=total, **kw)
+    assert f.process_device(d, 1, total) == 0
+    assert f.finish() >= 0
+    hc = f.hitcount.astype(np.int64)
+    assert np.all(hc.sum(0) == total), "a column's counts do not sum to the frame length"
+    wf = f.waterfall
+    hist, spec = canon_bits(f.histogram), canon_bits(f.spectrum)
+    # determinism: a second instance, same frame -> identical bits everywhere
+    f2 = amd.Fosphor(max_spectra=total, **kw)
+    assert f2.process_device(d, 1, total) == 0 and f2.finish() >= 0
+    assert np.array_equal(f2.hitcount, hc)
+    assert np.array_equal(canon_bits(f2.waterfall), canon_bits(wf))
+    assert np.array_equal(canon_bits(f2.histogram), hist) and np.array_equal(canon_bits(f2.spectrum), spec)
+    f2.close()
+    # additivity: counts of the frame = counts of its first 16 spectra + counts of the other 1008
+    a = amd.Fosphor(max_spectra=16, **kw)
+    b = amd.Fosphor(max_spectra=1008, **kw)
+    assert a.process_device(d[:16 * n], 1, 16) == 0 and b.process_device(d[16 * n:], 1, 1008) == 0
+    hc_a, hc_b = a.hitcount.astype(np.int64), b.hitcount.astype(np.int64)
+    assert np.array_equal(hc, hc_a + hc_b), "hit counts are not additive over the frame's spectra"
+    # the 16-spectrum slice against the oracle: counts bit-exact, its rows of the FULL frame's waterfall in tolerance
+    x16 = d[:16 * n].cpu().numpy().astype(np.float32)
+    o = Oracle(fft_len_log=16, n_bins=nb, wf_rows=rows)
+    assert o.process(x16, strict=False, nthreads=8) == 0
+    assert np.array_equal(hc_a, o.hitcount.T.astype(np.int64)), "16-spectrum slice: hit counts differ from the oracle"
+    assert_close(wf[:16], o.waterfall[:16], "C5 full frame: waterfall rows of the first 16 spectra")
+    assert_close(a.waterfall[:16], o.waterfall[:16], "C5 16-spectrum launch: waterfall rows")
+    for q in (f, a, b):
+        q.close()
 
 
 def _c5_outputs(f):
