@@ -241,28 +241,6 @@ static unsigned dep_event_flags(void)
 	return (e && *e == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
-/* The instance's own streams.  FOSPHOR_AMD_CU_SPLIT=n (experiment): the count / merge streams (kind 1) are
- * confined to the last n bits of the 256-bit CU mask and the FFT streams (kind 0) to the others, so that K2 / K3 do not take
- * LDS-pipe and issue slots on the CUs K1 runs on.  0 / unset: no masks (every kernel may use every CU). */
-static hipError_t create_stream(hipStream_t *st, int kind)
-{
-	static const int split = [] { const char *e = getenv("FOSPHOR_AMD_CU_SPLIT"); const int v = e ? atoi(e) : 0;
-	                              return (v > 0 && v < 256) ? v : 0; }();
-	if (!split)
-		return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-	uint32_t mask[8];
-	for (int w = 0; w < 8; w++) {
-		mask[w] = 0;
-		for (int b = 0; b < 32; b++) {
-			const int bit = w * 32 + b;
-			const int in_k23 = bit >= 256 - split;
-			if ((kind == 1) == (in_k23 != 0))
-				mask[w] |= 1u << b;
-		}
-	}
-	return hipExtStreamCreateWithCUMask(st, 8, mask);
-}
-
 extern "C" const char *fosphor_amd_version(void) { return FOSPHOR_AMD_VERSION; }
 
 extern "C" void fosphor_release(struct fosphor *self)
@@ -386,7 +364,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	if (cfg && cfg->stream) {
 		self->stream = (hipStream_t)cfg->stream;
 	} else {
-		HIP_TRY(create_stream(&self->stream, 0), "hipStreamCreate");
+		HIP_TRY(hipStreamCreateWithFlags(&self->stream, hipStreamNonBlocking), "hipStreamCreate");
 		self->own_stream = 1;
 	}
 
@@ -408,7 +386,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	self->k1_streams[0] = self->stream;
 	for (int i = 1; i < self->n_k1_streams; i++) {
-		HIP_TRY(create_stream(&self->k1_streams[i], 0), "hipStreamCreate (FFT stream)");
+		HIP_TRY(hipStreamCreateWithFlags(&self->k1_streams[i], hipStreamNonBlocking), "hipStreamCreate (FFT stream)");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1s_done[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
@@ -437,8 +415,8 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	/* host staging slot: the reference's cap of 1024 spectra per call (cl.c:885), or this instance's */
 	self->stage_samples = (size_t)self->n * (self->max_spectra < 1024 ? self->max_spectra : 1024);
-	HIP_TRY(create_stream(&self->stream2, 1), "hipStreamCreate (count stream)");
-	HIP_TRY(create_stream(&self->stream3, 1), "hipStreamCreate (merge stream)");
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
+	HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k2_done[i], dep_event_flags()), "create event");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
@@ -679,6 +657,15 @@ static int pick_tile(const struct fosphor *self, int total, int batch)
 		/* a cluster owns whole tiles: the largest tile that still gives each of the 32 clusters one */
 		for (int t = 64; t >= 8; t >>= 1)
 			if (batch % t == 0 && total / t >= 32)
+				return t;
+		return 4;
+	}
+	if (self->log2n == 13) {
+		/* one work-group per CU walks whole tiles; inside a tile the overlapped half of a window is reused from registers,
+		 * so long tiles fetch less (tile 32 at 50 % overlap: 33 half-windows for 32 spectra); two tiles per CU and more keep
+		 * the tail short */
+		for (int t = 32; t >= 8; t >>= 1)
+			if (batch % t == 0 && total / t >= 512)
 				return t;
 		return 4;
 	}

@@ -1012,6 +1012,260 @@ void k1big_fft_bin(const K1Params p)
 }
 
 /* ------------------------------------------------------------------------ */
+/* K1 for N = 8192: 512 threads per spectrum, 16 points per thread            */
+/* ------------------------------------------------------------------------ */
+/* The same plan as k1big_fft_bin<13> (radix-8 passes p = 1, 8, 64, 512 and the radix-2 pass p = 4096 over 1024 virtual
+ * work-items of 8 points, fft.cl:278-350,397-466 generalised) with the structure of the 1024-point kernel:
+ *   - a thread runs TWO virtual work-items per pass: (2 th, 2 th + 1) in pass 1 -- what 16-byte IQ loads deliver --
+ *     and (th, th + 512) in passes 2-4, whose twiddle index k = i & (p - 1) is the same for both.  With both items
+ *     of a pair in one thread the exchange between the p = 512 pass and the radix-2 pass is the identity (item
+ *     th + 512 v stores e = 4096 v + th + 512 jj, the radix-2 butterflies of the thread are (th + 512 jj, + 4096)):
+ *     three exchanges through LDS instead of five, each with ONE barrier (two 64 KiB slabs used alternately: the
+ *     barrier behind the stores of an exchange also proves that every thread has finished the loads of the exchange
+ *     before the previous one, i.e. of the slab written next);
+ *   - everything a thread needs from the tables is fixed per thread: 16 window taps and 3 x 7 twiddles of the
+ *     radix-8 passes sit in 58 registers; the radix-2 pass's 4096 twiddles in the 32 KiB of LDS the slabs leave;
+ *   - the overlap of overlap_cc (overlap_cc_impl.cc:64-79) lives in REGISTERS: a thread holds the raw IQ of elements
+ *     (2 th, 2 th + 1) + 1024 j, j < 8; the next window of a tile starts hop = N / R samples later, i.e. 8 / R strides
+ *     of 1024 -- its element j is this window's element j + 8 / R of the same thread.  With R = 2 (BASELINE C3) a
+ *     spectrum costs four 16-byte loads per thread: every sample of the stream is fetched once (the first spectrum of a
+ *     tile loads all eight).  The loads for the next spectrum are issued before the FFT of the current one.
+ * One work-group (8 waves, <= 256 registers) per CU.  Same arithmetic and outputs as k1big_fft_bin<13> (bit-identical
+ * FFT, bins, rows; 16-bit bin indices, 2 spectra per dword). */
+/* Work-group barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its outstanding
+ * global loads and stores (__syncthreads() also drains vmcnt, which would park every wave of the work-group behind the
+ * IQ requested for the NEXT spectrum).  Nothing is handed from thread to thread through global memory in these kernels. */
+static __device__ __forceinline__ void wg_barrier_lds()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool WRITE_FFT>
+__global__ __launch_bounds__(512, 2)
+void k1w_fft_bin(const K1Params p)
+{
+	constexpr int N = 8192, TH = 512;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	/* two 64 KiB slabs; a spectrum's three exchanges use A, B, A and the next spectrum's B, A, B: whenever a slab is stored
+	 * to, a barrier lies between those stores and the last loads from it */
+	v2f *slab0 = reinterpret_cast<v2f *>(smem_raw);
+	v2f *slab1 = slab0 + N;
+	v2f *twr = slab0 + 2 * N;		/* radix-2 twiddles [4096]: the last 32 KiB of the CU's 160 KiB */
+
+	const int th = threadIdx.x;
+	const int ntiles = p.total / p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	/* ---- per-thread constants ------------------------------------------------ */
+	v2f win[8];			/* taps of elements (2 th, 2 th + 1) + 1024 j */
+	v2f tw8[7], tw64[7], tw512[7];	/* k = th & 7, th & 63, th (both items of a pair) */
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		win[j] = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * j);
+		twr[th + 512 * j] = twg[p.tw_off[3] + th + 512 * j];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int n = 0; n < 7; n++) {
+		tw8[n]   = twg[p.tw_off[0] + (th & 7) * 7 + n];
+		tw64[n]  = twg[p.tw_off[1] + (th & 63) * 7 + n];
+		tw512[n] = twg[p.tw_off[2] + th * 7 + n];
+	}
+
+	/* ---- LDS addressing (8-byte elements, phys(e) = e ^ ((e >> 3) & 15) as in the other kernels) ----
+	 * loads of every pass: e = th + 512 m -> phys = rd + 512 m;  stores: pass 1 e = 16 th + 8 v + jj,
+	 * pass 2 e = 64 (th >> 3) + (th & 7) + 4096 v + 8 jj, pass 3 e = 512 (th >> 6) + (th & 63) + 4096 v + 64 jj */
+	const int rd  = th ^ ((th >> 3) & 15);
+	const int e1a = 16 * th, e1b = 16 * th + 8;
+	const int st1a = e1a ^ ((e1a >> 3) & 15), st1b = e1b ^ ((e1b >> 3) & 15);	/* ^ jj below: jj < 8 touches bits 0-2 only */
+	const int e2 = 64 * (th >> 3) + (th & 7);
+	const int e3 = 512 * (th >> 6) + (th & 63);
+	const int st3 = e3 ^ ((e3 >> 3) & 15);						/* + 64 jj: (64 jj >> 3) & 15 = (8 jj) & 15 */
+
+	/* hop = N / R with R = 2, 4, 8: the next window's element j is this window's element j + shift of the same thread */
+	const int shift = (p.hop == N / 2) ? 4 : (p.hop == N / 4) ? 2 : (p.hop == N / 8) ? 1 : 0;
+
+	v4f q[8];			/* raw IQ of the spectrum to be processed next */
+	uint16_t *bins16 = reinterpret_cast<uint16_t *>(p.bins);
+
+	/* Epilogue of columns [M0, M1) of spectrum tp, whose FFT is in xo: log-power, exact 16-bit bin, live / max, waterfall row
+	 * (display.cl:136-150,161-168).  Per column, nothing carried from column to column: it is cut into three pieces that
+	 * run between the LDS stores of the NEXT spectrum's exchanges and the barrier behind them, i.e. while this wave
+	 * would otherwise wait for the slowest one. */
+#define K1W_EPI(M0, M1, tp) do { \
+		const bool _row = ((tp) >= p.wf_first); \
+		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + th; \
+		uint16_t *_bd = bins16 + ((size_t)((tp) >> 1) * N + th) * 2 + ((tp) & 1); \
+		_Pragma("unroll") \
+		for (int m = (M0); m < (M1); m++) { \
+			float l2v; uint32_t ab; \
+			const float rr = bin_fast(xo[m].x, xo[m].y, bk, &l2v, &ab); \
+			uint32_t bn = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top); \
+			if (ab > __float_as_uint(bk.amb)) {		/* rare: decided against the exact thresholds */ \
+				float nl2; \
+				bn = bin_exact(xo[m].x, xo[m].y, l2v, (int)bn, bk.thr, bk.nb, &nl2); \
+				l2v = nl2; \
+			} \
+			_bd[2 * TH * m] = (uint16_t)bn; \
+			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
+			vmax[m] = max_f32(vmax[m], l2v); \
+			if (_row) _wf[TH * m] = l2v * F_HALF_LOG10_2; \
+		} \
+	} while (0)
+
+	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	const int t0 = tile * p.tile;
+	float live[16], vmax[16];
+#pragma unroll
+	for (int m = 0; m < 16; m++) { live[m] = 0.0f; vmax[m] = vmax_init; }
+
+	{
+		const float2 *src = p.iq + (size_t)t0 * p.hop + 2 * th;
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
+	}
+
+	v2f xo[16];			/* FFT of the previous spectrum of the tile, its epilogue still to do */
+#pragma unroll
+	for (int m = 0; m < 16; m++) xo[m] = v2f{ 0.0f, 0.0f };
+
+#pragma unroll 1
+	for (int g = 0; g < p.tile; g++) {
+		const int t = t0 + g;
+		const bool have_prev = g > 0;			/* uniform */
+		v2f x[16];
+		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
+
+		/* window (fft.cl:415-417): x[2 j + v] = element 2 th + v + 1024 j */
+#pragma unroll
+		for (int j = 0; j < 8; j++) {
+			x[2 * j]     = mul_bcast_lo(v2f{ q[j].x, q[j].y }, win[j]);
+			x[2 * j + 1] = mul_bcast_hi(v2f{ q[j].z, q[j].w }, win[j]);
+		}
+
+		/* raw IQ of the next spectrum of this tile: shared elements move down, the new ones are requested now */
+		if (g + 1 < p.tile) {
+			const float2 *src = p.iq + (size_t)(t + 1) * p.hop + 2 * th;
+			if (shift == 4) {
+#pragma unroll
+				for (int j = 0; j < 4; j++) q[j] = q[j + 4];
+#pragma unroll
+				for (int j = 4; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
+			} else if (shift == 2) {
+#pragma unroll
+				for (int j = 0; j < 6; j++) q[j] = q[j + 2];
+#pragma unroll
+				for (int j = 6; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
+			} else if (shift == 1) {
+#pragma unroll
+				for (int j = 0; j < 7; j++) q[j] = q[j + 1];
+				q[7] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * 7));
+			} else {
+#pragma unroll
+				for (int j = 0; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
+			}
+		}
+
+		/* ---- pass 1: p = 1, items i = 2 th + v, outputs e = 8 i + jj -> slab0 ---- */
+#pragma unroll
+		for (int v = 0; v < 2; v++) {
+			v2f r[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				slab0[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
+		}
+		if (have_prev) K1W_EPI(0, 6, t - 1);
+		wg_barrier_lds();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = slab0[rd + 512 * m];		/* item th + 512 v reads e = i + 1024 j = th + 512 (v + 2 j) */
+
+		/* ---- pass 2: p = 8, items i = th + 512 v, k = th & 7 -> slab1 ---- */
+#pragma unroll
+		for (int v = 0; v < 2; v++) {
+			v2f r[8];
+			r[0] = x[v];
+#pragma unroll
+			for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw8[j - 1]);
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				slab1[swz(e2 + 8 * jj) + 4096 * v] = r[R8_PERM(jj)];
+		}
+		if (have_prev) K1W_EPI(6, 11, t - 1);
+		wg_barrier_lds();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = slab1[rd + 512 * m];
+
+		/* ---- pass 3: p = 64, k = th & 63 -> slab0 ---- */
+#pragma unroll
+		for (int v = 0; v < 2; v++) {
+			v2f r[8];
+			r[0] = x[v];
+#pragma unroll
+			for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw64[j - 1]);
+			dft8(r, s12);
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++)
+				slab0[(st3 ^ ((8 * jj) & 15)) + 64 * jj + 4096 * v] = r[R8_PERM(jj)];
+		}
+		if (have_prev) K1W_EPI(11, 16, t - 1);
+		wg_barrier_lds();
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			x[m] = slab0[rd + 512 * m];
+
+		/* ---- pass 4: p = 512, k = th; its outputs ARE the radix-2 inputs of this thread ---- */
+		{
+			v2f y[16];
+#pragma unroll
+			for (int v = 0; v < 2; v++) {
+				v2f r[8];
+				r[0] = x[v];
+#pragma unroll
+				for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw512[j - 1]);
+				dft8(r, s12);
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++) y[jj + 8 * v] = r[R8_PERM(jj)];
+			}
+			/* ---- radix 2, p = 4096 (fft.cl:428-458): (jb, jb + 4096), jb = th + 512 c -> columns th + 512 m ---- */
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				v2f a = y[c];
+				v2f b = c_mul(y[c + 8], twr[th + 512 * c]);
+				DFT2(a, b);
+				xo[c] = a;
+				xo[c + 8] = b;
+			}
+		}
+
+		if (WRITE_FFT) {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + th + TH * m] = xo[m];
+		}
+	}
+	K1W_EPI(0, 16, t0 + p.tile - 1);		/* the tile's last spectrum */
+
+	float2 *pp2 = p.partial + (size_t)tile * N + th;
+#pragma unroll
+	for (int m = 0; m < 16; m++)
+		pp2[TH * m] = make_float2(live[m] * F_HALF_LOG10_2,
+			(vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
+	}
+#undef K1W_EPI
+}
+
+/* ------------------------------------------------------------------------ */
 /* K1 for N = 65536: two LDS stages                                           */
 /* ------------------------------------------------------------------------ */
 /* The plan for N = 8^5 * 2 is five radix-8 Stockham passes (p = 1, 8, 64, 512, 4096) and the
@@ -1715,6 +1969,27 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		}
 		if (p.log2n != 13)
 			return hipErrorInvalidValue;
+		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); needs 16-byte aligned
+		 * windows (even hop).  FOSPHOR_AMD_K1W=0: the general kernel. */
+		static const bool k1w_on = [] { const char *e = getenv("FOSPHOR_AMD_K1W"); return !(e && *e == '0'); }();
+		if (k1w_on && !(p.hop & 1)) {
+			constexpr int ldsw = 2 * 8192 * 8 + 4096 * 8;	/* two slabs + the radix-2 twiddles: 160 KiB */
+			static bool attr_w = false;
+			if (!attr_w) {
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1w_fft_bin<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+				if (e == hipSuccess)
+					e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1w_fft_bin<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+				if (e != hipSuccess)
+					return e;
+				attr_w = true;
+			}
+			const int bw = tiles < 256 ? tiles : 256;	/* one 8-wave work-group per CU */
+			if (p.fft_out)
+				hipLaunchKernelGGL(k1w_fft_bin<true>, dim3(bw), dim3(512), ldsw, s, p);
+			else
+				hipLaunchKernelGGL(k1w_fft_bin<false>, dim3(bw), dim3(512), ldsw, s, p);
+			return hipGetLastError();
+		}
 		constexpr int N = 8192;
 		constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;	/* exchange slab + twiddle table + window: 160 KiB */
 		int blocks = tiles < 256 ? tiles : 256;		/* one work-group (16 waves, 128 VGPRs) per CU */
