@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
-"""One compact line from a bench.py JSON line on stdin: bline.py <label>"""
+"""One compact line from a bench.py JSON line: bline.py <label> < file   or   bline.py <label> <file>   or   bline.py <file>
+(a file name is never waited for on stdin: an earlier form of this tool did, and a gpurun call sat on it until its time limit)."""
 import json
+import os
 import sys
 
 label = sys.argv[1] if len(sys.argv) > 1 else ""
+src = sys.stdin
+if len(sys.argv) > 2:
+    src = open(sys.argv[2])
+elif label and os.path.isfile(label):
+    src = open(label)
 line = ""
-for l in sys.stdin:
+for l in src:
     if l.startswith("{"):
         line = l
 if not line:

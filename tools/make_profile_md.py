@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/<tag>/ (written by tools/profile_r02.sh) -> profiles/<tag>.md: bench lines, kernel stats of our kernels,
+"""gpurun_out/<tag>/ (written by tools/profile_round.sh) -> profiles/<tag>.md: bench lines, kernel stats of our kernels,
 union table, PMC table.   python3 tools/make_profile_md.py <tag> "<title>" ["note"]"""
 import csv
 import json
@@ -27,7 +27,7 @@ hdr, rows = rows[0], [r for r in rows[1:] if r and "fosphor_amd" in r[0] or (r a
 keep = lambda txt: "\n".join(l for l in txt.split("\n") if "at::native" not in l)
 union = keep(open(os.path.join(out, "kernel_union.md")).read())
 pmc = keep(open(os.path.join(out, "pmc.md")).read())
-md = "# %s\n\nProduced by `bash tools/profile_r02.sh %s ...` on a 1xMI355X box (one gpurun call).  %s\n\n" % (title, tag, note)
+md = "# %s\n\nProduced by `bash tools/profile_round.sh %s ...` on a 1xMI355X box (one gpurun call).  %s\n\n" % (title, tag, note)
 md += "## 1. bench line, driver arguments (`--steps 20 --warmup 5`), un-profiled\n\n```\n%s\n```\n\n" % b
 if bd:
     md += "Default arguments, same box: value %.0f MS/s.  " % json.loads(bd)["value"]
@@ -37,6 +37,6 @@ md += "## 2. rocprofv3 --kernel-trace --stats (whole process: pre-conditioning, 
 md += ",".join(hdr) + "\n" + "\n".join(",".join(r) for r in rows) + "\n```\n\n"
 md += "Union of overlapping dispatches (`tools/kernel_union.py`, dispatches of 3 us and more):\n\n" + union + "\n"
 md += "## 3. HBM counters (`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE GRBM_GUI_ACTIVE` passes; KiB per dispatch, means; "
-md += "FETCH_SIZE x 2 for 8- and 16-byte-per-lane streaming loads on gfx950, uncalibrated for 4-byte loads)\n\n" + pmc
+md += "FETCH_SIZE x 2 = bytes on gfx950 for 4-, 8- and 16-byte-per-lane loads, plain and non-temporal: `profiles/r03_calib.md`)\n\n" + pmc
 open(os.path.join(ROOT, "profiles", tag + ".md"), "w").write(md)
 print("wrote profiles/%s.md (%d bytes)" % (tag, len(md)))
