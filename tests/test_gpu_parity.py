@@ -484,6 +484,30 @@ def test_c3_full_batch_properties(amd, torch_cuda, oracle_built):
     f.close(); f2.close()
 
 
+def test_buffers_without_hitcount_view(amd, torch_cuda, oracle_built, monkeypatch):
+    """fosphor_amd_get_buffers_nohc: the pointers / ring position / scale a front end polls per frame, without the hit-count view
+    (no export kernel, no wait).  The view made afterwards is still that of the last batch -- also with the single-stream
+    pipeline (FOSPHOR_AMD_OVERLAP=0), where the count kernel does not run on the count/merge stream."""
+    torch = torch_cuda
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("FOSPHOR_AMD_OVERLAP", overlap)
+        f = amd.Fosphor(max_spectra=256)
+        o = Oracle()
+        x = add_tone(gaussian_iq(4 * 64 * 1024, 61), 0.1, 0.2)
+        assert f.process_device(torch.from_numpy(x).cuda(), 4, 64) == 0
+        b0 = f.buffers(hitcount=False)			# nothing synchronised yet
+        assert not b0.d_hitcount and b0.d_histogram and b0.d_waterfall and b0.d_spectrum
+        assert b0.waterfall_pos == 256 and (b0.fft_len, b0.n_bins, b0.wf_rows) == (1024, 128, 1024)
+        b1 = f.buffers()				# makes the view, behind the count kernel that wrote the 16-bit counts
+        assert b1.d_hitcount and b1.d_histogram == b0.d_histogram and b1.waterfall_pos == b0.waterfall_pos
+        from gr_fosphor_amd.dist import wrap_device_array
+        hc = wrap_device_array(b1.d_hitcount, (128, 1024), torch.int32).cpu().numpy().view(np.uint32)	# the view is complete when buffers() returns
+        for k in range(4):
+            assert o.process(x[k * 64 * 1024:(k + 1) * 64 * 1024]) == 0
+        assert np.array_equal(hc, o.hitcount.T), "overlap=%s" % overlap
+        f.close()
+
+
 def test_table_change_between_relaxed_calls(amd, torch_cuda, oracle_built, monkeypatch):
     """Relaxed input ordering: the FFT kernels of a call may still be running on the second FFT stream when the next call
     begins.  A window / power-range change between two such calls must not reach the earlier call's spectra (the tables are
@@ -968,7 +992,17 @@ def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built)
     for k in range(0, n_spec, 512):
         o.process(x[k * 1024:(k + 512) * 1024], nthreads=8)
     assert_close(wf, o.waterfall, "sink waterfall after a native feed")
+    # a rate, not only a count: the same samples again, several times (PCIe-inclusive; 4.65 GSamples/s measured with a 16 Mi
+    # FIFO on an idle box -- the floor here is a sixth of that, for a shared box and this 4 Mi FIFO)
+    reps = 8
+    dt = L.fosphor_amd_sink_feed(s, flat.ctypes.data, n_spec * 1024, 1 << 20, reps)
+    assert dt > 0
+    rate = reps * n_spec * 1024 / dt / 1e9
+    print("sink, native feed: %.2f GSamples/s through work()" % rate)
+    assert rate > 0.75, "streaming sink moved only %.2f GSamples/s" % rate
     L.fosphor_amd_sink_stop(s)
+    # a sink that is not running takes nothing and says so instead of blocking for ever (work() returns 0, the feed gives up)
+    assert L.fosphor_amd_sink_work(s, flat.ctypes.data, 1 << 16) == 0
     L.fosphor_amd_sink_free(s)
 
 
