@@ -76,13 +76,12 @@ class NativeComm:
     def __init__(self, lib, rank, world, broadcast_id=None):
         self.L, self.rank, self.world = lib, rank, world
         buf = (C.c_char * 128)()
-        if rank == 0:
-            rv = lib.fosphor_amd_comm_unique_id(buf)
-            if rv:
-                raise RuntimeError("fosphor_amd_comm_unique_id -> %d (is an RCCL library available?)" % rv)
-        ident = bytes(buf.raw)
+        rv0 = lib.fosphor_amd_comm_unique_id(buf) if rank == 0 else 0
+        ident = bytes(buf.raw) if not rv0 else b""	# an empty id tells the other ranks that rank 0 has none: nobody is left waiting
         if world > 1:
             ident = (broadcast_id or self._torch_broadcast)(ident if rank == 0 else None)
+        if not ident:
+            raise RuntimeError("fosphor_amd_comm_unique_id failed on rank 0 (%d): is an RCCL library available?" % rv0)
         self.h = C.c_void_p()
         rv = lib.fosphor_amd_comm_init(C.byref(self.h), world, rank, ident)
         if rv:

@@ -129,6 +129,26 @@ if fail_on >= 0 and rank != fail_on:
     assert [o.kind for o in made] == ["native", "torch"] and made[0].closed and not made[1].closed
 if rank == fail_on:
     assert logs and "unavailable" in logs[0]
+# NativeComm's id hand-off: rank 0's 128-byte id reaches every rank; if rank 0 cannot make one, EVERY rank raises (nobody is
+# left waiting in the broadcast)
+from gr_fosphor_amd.dist import NativeComm
+class FakeLib:
+    def __init__(self, fail): self.fail, self.seen = fail, None
+    def fosphor_amd_comm_unique_id(self, buf):
+        if self.fail: return -38
+        buf.raw = bytes(range(128)); return 0
+    def fosphor_amd_comm_init(self, href, world, rank, ident):
+        self.seen = bytes(ident); return 0
+    def fosphor_amd_comm_destroy(self, h): return 0
+fl = FakeLib(False)
+nc = NativeComm(fl, rank, world)
+assert fl.seen == bytes(range(128)), "rank %d got a different id" % rank
+nc.h = None
+try:
+    NativeComm(FakeLib(True), rank, world)
+    raise SystemExit("rank %d: no error although rank 0 has no id" % rank)
+except RuntimeError as e:
+    assert "rank 0" in str(e)
 # every rank ended on the same transport
 kinds = [None] * world
 dist.all_gather_object(kinds, obj.kind)
