@@ -2079,7 +2079,7 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
  * (The previous layout, display.cl:96,176's [bin][16] with 4 spectra x 16 columns per wave,
  * had 4 lanes per column in every atomic instruction and kept the LDS pipe busy ~3x longer.) */
 #ifndef K2_INFLIGHT
-#define K2_INFLIGHT 4
+#define K2_INFLIGHT 8		/* 45 VGPRs: still beside two K1 waves of 228 on a SIMD; 4 -> 8: K2 59 -> 51 us beside K1, path +1.6 % */
 #endif
 /* NW waves per work-group: 4 where the kernel has to fit beside K1 (8-bit indices, N = 1024); 16 for the
  * 16-bit-index geometries, whose grids are small (N/64 x chunks) and whose rows are latency-bound */
@@ -2087,7 +2087,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW)
 void k2_count(const K2Params p)
 {
-	extern __shared__ uint32_t h[];			/* [n_bins][32] packed pairs */
+	extern __shared__ __attribute__((aligned(16))) uint32_t h[];	/* [n_bins][32] packed pairs */
 	__shared__ float red_s[NW][64], red_m[NW][64];
 
 	const int tid  = threadIdx.x;
@@ -2103,8 +2103,12 @@ void k2_count(const K2Params p)
 	const uint32_t inc = (lane & 32) ? 0x10000u : 1u;
 
 	__shared__ uint32_t rowbits[16];		/* n_bins <= 512 */
-	for (int i = tid; i < nb * 32; i += 64 * NW)
-		h[i] = 0;
+	{
+		/* 16 bytes per instruction (n_bins is a multiple of 16: nb * 32 dwords = whole uint4s) */
+		uint4 *h4 = reinterpret_cast<uint4 *>(h);
+		for (int i = tid; i < nb * 8; i += 64 * NW)
+			h4[i] = make_uint4(0u, 0u, 0u, 0u);
+	}
 	if (tid < 16)
 		rowbits[tid] = 0;
 	__syncthreads();
@@ -2214,9 +2218,13 @@ void k2_count(const K2Params p)
 				p.rowmask[((size_t)blockIdx.x * p.mask_words + tid) * p.mask_stride + c] = rowbits[tid];
 			return;
 		}
+		{
+			const uint4 *h4 = reinterpret_cast<const uint4 *>(h);
+			uint4 *d4 = reinterpret_cast<uint4 *>(d);
 #pragma unroll 2
-		for (int i = tid; i < nb * 32; i += 64 * NW)
-			d[i] = h[i];
+			for (int i = tid; i < nb * 8; i += 64 * NW)
+				d4[i] = h4[i];
+		}
 		return;
 	}
 	/* (rolled loops: the register budget of this kernel is what lets it share a SIMD with K1) */
