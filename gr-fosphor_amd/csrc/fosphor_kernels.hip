@@ -113,28 +113,16 @@ static __device__ __forceinline__ v2f mul_bcast_hi(v2f x, v2f w)
 #define R8_PERM(jj) (((jj) == 0) ? 0 : ((jj) == 1) ? 4 : ((jj) == 2) ? 2 : ((jj) == 3) ? 6 : \
                      ((jj) == 4) ? 1 : ((jj) == 5) ? 5 : ((jj) == 6) ? 3 : 7)
 
-/* Intra-wave LDS exchange.  All DS instructions of one wave enter the LDS queue in program
- * order and are executed in that order, so a ds_read issued after the ds_writes of the other
- * lanes of the SAME wave observes them, and a later ds_write cannot overtake an earlier
- * ds_read -- no s_waitcnt is needed between the store phase and the load phase of an
- * exchange (the loads' own lgkmcnt waits before their first use remain).  What must not
- * happen is the COMPILER moving a load above a store it cannot prove aliases: the wave
- * barrier + compiler-only memory clobber pin program order without emitting an instruction.
- * K1_LDS_FENCE=1 restores the conservative release/acquire fences (s_waitcnt lgkmcnt(0)). */
-#ifndef K1_LDS_FENCE
-#define K1_LDS_FENCE 1
-#endif
+/* Intra-wave LDS exchange: the store phase and the load phase of an exchange are separated by wavefront-scope release /
+ * acquire fences around a wave barrier (the compiler must not move a load above a store it cannot prove aliases; the fences
+ * cost an s_waitcnt lgkmcnt(0) each).  In principle program order alone would do -- all DS instructions of one wave execute in
+ * order -- and a build with compiler-only barriers was measured in round 3: 519-525 against 523-526 GSamples/s, nothing; the
+ * conservative form stays. */
 static __device__ __forceinline__ void wave_lds_sync()
 {
-#if K1_LDS_FENCE
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-	asm volatile("" ::: "memory");
-	__builtin_amdgcn_wave_barrier();
-	asm volatile("" ::: "memory");
-#endif
 }
 
 /* ------------------------------------------------------------------------ */
@@ -614,9 +602,6 @@ hipError_t launch_k1_traffic_twin(const K1Params &p, hipStream_t s)
 #ifndef K1V2_WAVES_PER_SIMD
 #define K1V2_WAVES_PER_SIMD 3
 #endif
-#ifndef K1V2_TW_LDS
-#define K1V2_TW_LDS 0			/* 1: pass-3 twiddles from LDS; 2: pass-2 and pass-3 */
-#endif
 
 static __device__ __forceinline__ void load_iq8(v2f (&x)[8], const float2 *__restrict__ src)
 {
@@ -632,12 +617,6 @@ void k1v2_fft_bin(const K1Params p)
 	__shared__ v2f   buf[kN];			/* 8 KiB exchange slab of the work-group's spectrum */
 	__shared__ v2f   tw4_tab[512];
 	__shared__ float win_tab[kN];
-#if K1V2_TW_LDS >= 1
-	__shared__ v2f   tw3_tab[7][64];		/* [n-1][k] */
-#endif
-#if K1V2_TW_LDS >= 2
-	__shared__ v2f   tw2_tab[7][8];
-#endif
 
 	const int lane   = threadIdx.x & 63;
 	const int w      = threadIdx.x >> 6;		/* wave = virtual-item half */
@@ -651,31 +630,15 @@ void k1v2_fft_bin(const K1Params p)
 		win_tab[i] = p.win[i];
 	for (int i = threadIdx.x; i < 512; i += 128)
 		tw4_tab[i] = twg[kTw4Off + i];
-#if K1V2_TW_LDS >= 1
-	for (int i = threadIdx.x; i < 7 * 64; i += 128)
-		tw3_tab[i % 7][i / 7] = twg[kTw3Off + i];
-#endif
-#if K1V2_TW_LDS >= 2
-	if (threadIdx.x < 56)
-		tw2_tab[threadIdx.x % 7][threadIdx.x / 7] = twg[kTw2Off + threadIdx.x];
-#endif
 	__syncthreads();
 
 	/* per-lane twiddles: k = i & 7 and k = i & 63 do not depend on w */
-#if K1V2_TW_LDS < 2
 	v2f tw2[7];
-#endif
-#if K1V2_TW_LDS < 1
 	v2f tw3[7];
-#endif
 #pragma unroll
 	for (int n = 0; n < 7; n++) {
-#if K1V2_TW_LDS < 2
 		tw2[n] = twg[kTw2Off + (lane & 7) * 7 + n];
-#endif
-#if K1V2_TW_LDS < 1
 		tw3[n] = twg[kTw3Off + lane * 7 + n];
-#endif
 	}
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
 
@@ -746,11 +709,7 @@ void k1v2_fft_bin(const K1Params p)
 			/* pass 2 (fft.cl:422-423) */
 #pragma unroll
 			for (int j = 1; j < 8; j++)
-#if K1V2_TW_LDS >= 2
-				r[j] = c_mul(r[j], tw2_tab[j - 1][lane & 7]);
-#else
 				r[j] = c_mul(r[j], tw2[j - 1]);
-#endif
 			dft8(r, s12);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
@@ -764,11 +723,7 @@ void k1v2_fft_bin(const K1Params p)
 			/* pass 3 (fft.cl:425-426) */
 #pragma unroll
 			for (int j = 1; j < 8; j++)
-#if K1V2_TW_LDS >= 1
-				r[j] = c_mul(r[j], tw3_tab[j - 1][lane]);
-#else
 				r[j] = c_mul(r[j], tw3[j - 1]);
-#endif
 			dft8(r, s12);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
