@@ -1037,7 +1037,9 @@ void k1w_fft_bin(const K1Params p)
 	const int rd  = th ^ ((th >> 3) & 15);
 	const int e1a = 16 * th, e1b = 16 * th + 8;
 	const int st1a = e1a ^ ((e1a >> 3) & 15), st1b = e1b ^ ((e1b >> 3) & 15);	/* ^ jj below: jj < 8 touches bits 0-2 only */
-	const int e2 = 64 * (th >> 3) + (th & 7);
+	/* pass 2: swz(64 (th >> 3) + (th & 7) + 8 jj) in closed form: bits 0-2 (th & 7) ^ jj, bit 3 (jj & 1) ^ ((th >> 3) & 1), bits 4-5
+	 * jj >> 1 -- one XOR with a constant per store */
+	const int st2 = 64 * (th >> 3) + 8 * ((th >> 3) & 1) + (th & 7);
 	const int e3 = 512 * (th >> 6) + (th & 63);
 	const int st3 = e3 ^ ((e3 >> 3) & 15);						/* + 64 jj: (64 jj >> 3) & 15 = (8 jj) & 15 */
 
@@ -1153,7 +1155,7 @@ void k1w_fft_bin(const K1Params p)
 			dft8(r, s12);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
-				slab1[swz(e2 + 8 * jj) + 4096 * v] = r[R8_PERM(jj)];
+				slab1[(st2 ^ (jj | (8 * (jj & 1)) | (16 * (jj >> 1)))) + 4096 * v] = r[R8_PERM(jj)];
 		}
 		if (have_prev) K1W_EPI(6, 11, t - 1);
 		wg_barrier_lds();
