@@ -58,7 +58,10 @@ bool fifo::sleep_until(Pred ready, int timeout_ms)
 		sleep_cv_.wait(lk, ready);
 		ok = true;
 	} else {
-		ok = sleep_cv_.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready);
+		/* (system_clock: libstdc++ then waits with pthread_cond_timedwait, which ThreadSanitizer intercepts; the steady-clock
+		 * form uses pthread_cond_clockwait, which it does not and reports as a double lock.  The time-outs here are
+		 * 100 ms slices of a retry loop: a clock step costs one slice.) */
+		ok = sleep_cv_.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(timeout_ms), ready);
 	}
 	sleepers_.fetch_sub(1, std::memory_order_seq_cst);
 	return ok;

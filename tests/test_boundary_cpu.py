@@ -193,3 +193,29 @@ def test_fifo_semantics(amd):
     L.fosphor_amd_fifo_read_discard(f, 424)
     t.join(2.0); assert done
     L.fosphor_amd_fifo_free(f)
+
+
+def test_fifo_two_threads_under_thread_sanitizer(amd, tmp_path):
+    """The sink's FIFO is a single-producer / single-consumer ring on two atomic counters (lock-free unless a side has to
+    sleep).  tests/c/fifo_stress.cpp runs a producer and a consumer with random region sizes, blocking, non-blocking and timed
+    calls, checks that every sample arrives once and in order, and is built with -fsanitize=thread (CPU only: the sanitizer
+    instruments fosphor_sink.cpp itself; the rest of the library is linked as it is)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    exe = tmp_path / "fifo_stress"
+    libdir = os.path.dirname(amd.LIB_PATH)
+    cmd = [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c", "fifo_stress.cpp"), os.path.join(ROOT, "gr-fosphor_amd", "csrc", "fosphor_sink.cpp"),
+           "-L" + libdir, "-lfosphor_amd", "-L/opt/rocm/lib", "-lamdhip64", "-pthread",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0 and "tsan" in (b.stderr or "").lower():
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([str(exe), "3000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert "0 bad" in r.stdout
