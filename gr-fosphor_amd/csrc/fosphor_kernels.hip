@@ -2035,6 +2035,9 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
  * work-group of this kernel sit beside the two K1 work-groups of a CU.
  * (The previous layout, display.cl:96,176's [bin][16] with 4 spectra x 16 columns per wave,
  * had 4 lanes per column in every atomic instruction and kept the LDS pipe busy ~3x longer.) */
+#ifndef K2_INFLIGHT16
+#define K2_INFLIGHT16 4		/* the 16-bit-index geometries (16-wave work-groups): measured at N = 8192, 4 / 8 / 16 -> 62 / 67 / 72 us */
+#endif
 #ifndef K2_INFLIGHT
 #define K2_INFLIGHT 8		/* 45 VGPRs: still beside two K1 waves of 228 on a SIMD; 4 -> 8: K2 59 -> 51 us beside K1, path +1.6 % */
 #endif
@@ -2078,13 +2081,13 @@ void k2_count(const K2Params p)
 		const uint32_t nq16 = p.chunk >> 1, n = p.n;
 		uint32_t q = wv;
 #pragma unroll 1
-		for (; q + NW * (K2_INFLIGHT - 1) < nq16; q += NW * K2_INFLIGHT) {
-			uint32_t v[K2_INFLIGHT];
+		for (; q + NW * (K2_INFLIGHT16 - 1) < nq16; q += NW * K2_INFLIGHT16) {
+			uint32_t v[K2_INFLIGHT16];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT; u++)
+			for (int u = 0; u < K2_INFLIGHT16; u++)
 				v[u] = src16[(q + NW * u) * n + lane];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT; u++) {
+			for (int u = 0; u < K2_INFLIGHT16; u++) {
 				atomicAdd(&h[(v[u] & 0xffffu) * 32 + hcol], inc);
 				atomicAdd(&h[(v[u] >> 16) * 32 + hcol], inc);
 			}
