@@ -435,6 +435,11 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		 * (measured: 134-136 -> 142-144 GSamples/s).  FOSPHOR_AMD_OVERLAP=1 keeps the streams. */
 		if (self->log2n == 16 && self->k1h_fused && !(e && *e == '1'))
 			self->overlap = 0;
+		/* N = 8192: the FFT kernel owns every CU's LDS and registers, so count and merge cannot run beside it either way; on one
+		 * stream the kernel boundaries are cheaper than cross-stream events (measured 286.6 / 287.8 / 287.1 against 286.1 / 284.7 /
+		 * 283.5 GSamples/s), and K1's busy time is no longer stretched by launches waiting for each other (0.363 vs 0.29-0.345). */
+		if (self->log2n == 13 && !(e && *e == '1'))
+			self->overlap = 0;
 		e = getenv("FOSPHOR_AMD_K1");
 		self->k1_variant = (e && *e == '2') ? 2 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
