@@ -2319,7 +2319,8 @@ hipError_t launch_k2c(const K2bParams &p, hipStream_t s)
  * 2: 32-bit counts, (d, e) evaluated per cell (batches beyond the table).  Separate instantiations keep
  * the common one (0) at a register budget that lets it share a SIMD with K1. */
 #ifndef K3_ROWS
-#define K3_ROWS 8
+#define K3_ROWS 2		/* rows in flight per wave of the sparse form: measured at N = 65536, 1 / 2 / 3 / 4 / 8 / 16 -> scan + merge 56 / 49 / 49 /
+				 * 53 / 61 / 114 us per frame (42 / 58 / 74 / ... / 256 VGPRs: more resident waves beat more requests per wave) */
 #endif
 #ifndef K3_BATCHES
 #define K3_BATCHES 2
