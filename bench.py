@@ -131,7 +131,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # (FOSPHOR_BENCH_BACKEND=gloo: test hook -- several ranks sharing ONE GPU, which RCCL refuses; tests/test_gpu_dist.py)
+        backend = os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from _pkg import gr_fosphor_amd
     from gr_fosphor_amd.dist import ShardedFosphor
