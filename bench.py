@@ -390,7 +390,16 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
+    # orderly shutdown on every rank: the library's communicator and instance first, then torch's process group
+    try:
+        if sf is not None:
+            sf.close()
+        else:
+            f.close()
+    except Exception as e:
+        sys.stderr.write("rank %d: shutdown: %s\n" % (rank, e))
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 
