@@ -2035,15 +2035,13 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
  * work-group of this kernel sit beside the two K1 work-groups of a CU.
  * (The previous layout, display.cl:96,176's [bin][16] with 4 spectra x 16 columns per wave,
  * had 4 lanes per column in every atomic instruction and kept the LDS pipe busy ~3x longer.) */
-#ifndef K2_INFLIGHT16
-#define K2_INFLIGHT16 4		/* the 16-bit-index geometries (16-wave work-groups): measured at N = 8192, 4 / 8 / 16 -> 62 / 67 / 72 us */
-#endif
-#ifndef K2_INFLIGHT
-#define K2_INFLIGHT 8		/* 45 VGPRs: still beside two K1 waves of 228 on a SIMD; 4 -> 8: K2 59 -> 51 us beside K1, path +1.6 % */
-#endif
+/* Independent index loads in flight per thread (IF): 8 for the per-batch chunks of the 1024-point path (45 VGPRs: still beside two K1
+ * waves of 228 on a SIMD; 4 -> 8: K2 59 -> 51 us beside K1, path +1.6 %; 12 / 16 = 61 / 63 VGPRs no longer fit there), 4 where a work-group
+ * counts several chunks (sharded frames: 532 against 527 GSamples/s) and for the 16-bit-index geometries (N = 8192: 4 / 8 / 16 -> 62 / 67 /
+ * 72 us). */
 /* NW waves per work-group: 4 where the kernel has to fit beside K1 (8-bit indices, N = 1024); 16 for the
  * 16-bit-index geometries, whose grids are small (N/64 x chunks) and whose rows are latency-bound */
-template <int NW>
+template <int NW, int IF>
 __global__ __launch_bounds__(64 * NW)
 void k2_count(const K2Params p)
 {
@@ -2081,13 +2079,13 @@ void k2_count(const K2Params p)
 		const uint32_t nq16 = p.chunk >> 1, n = p.n;
 		uint32_t q = wv;
 #pragma unroll 1
-		for (; q + NW * (K2_INFLIGHT16 - 1) < nq16; q += NW * K2_INFLIGHT16) {
-			uint32_t v[K2_INFLIGHT16];
+		for (; q + NW * (IF - 1) < nq16; q += NW * IF) {
+			uint32_t v[IF];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT16; u++)
+			for (int u = 0; u < IF; u++)
 				v[u] = src16[(q + NW * u) * n + lane];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT16; u++) {
+			for (int u = 0; u < IF; u++) {
 				atomicAdd(&h[(v[u] & 0xffffu) * 32 + hcol], inc);
 				atomicAdd(&h[(v[u] >> 16) * 32 + hcol], inc);
 			}
@@ -2103,13 +2101,13 @@ void k2_count(const K2Params p)
 		const uint32_t nq = p.chunk >> 2, n = p.n;
 		uint32_t q = wv;
 #pragma unroll 1
-		for (; q + NW * (K2_INFLIGHT - 1) < nq; q += NW * K2_INFLIGHT) {	/* independent loads in flight per thread */
-			uint32_t v[K2_INFLIGHT];
+		for (; q + NW * (IF - 1) < nq; q += NW * IF) {	/* independent loads in flight per thread */
+			uint32_t v[IF];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT; u++)
+			for (int u = 0; u < IF; u++)
 				v[u] = src[(q + NW * u) * n + lane];
 #pragma unroll
-			for (int u = 0; u < K2_INFLIGHT; u++) {
+			for (int u = 0; u < IF; u++) {
 				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
 				atomicAdd(&h[((v[u] >>  8) & 0xff) * 32 + hcol], inc);
 				atomicAdd(&h[((v[u] >> 16) & 0xff) * 32 + hcol], inc);
@@ -2208,9 +2206,11 @@ hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
 	const size_t lds = (size_t)p.n_bins * 32 * sizeof(uint32_t);
 	if (p.bins16)
-		hipLaunchKernelGGL(k2_count<16>, dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
+		hipLaunchKernelGGL((k2_count<16, 4>), dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
+	else if (p.chunk > 1024)
+		hipLaunchKernelGGL((k2_count<4, 4>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	else
-		hipLaunchKernelGGL(k2_count<4>, dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
+		hipLaunchKernelGGL((k2_count<4, 8>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	return hipGetLastError();
 }
 
