@@ -88,27 +88,42 @@ def parse():
 
 
 def cpu_baseline(bins, seconds):
-    """Oracle (CPU restatement of the reference kernels) on all host cores, bounded sample."""
+    """Oracle (CPU restatement of the reference kernels) on ALL online host cores, bounded sample.
+
+    One oracle instance parallelises a batch over at most 64 threads (its display stage has 64 column groups of 16,
+    cl.c:945-950), so a host with more cores runs cores // 64 independent instances side by side, each on its own
+    stream of batches -- the way several sink blocks would share the host.  cores = threads actually used."""
+    import threading
     from oracle_lib import Oracle, build_oracle, gaussian_iq
     build_oracle(ref=False)
-    cores = os.cpu_count() or 1
-    nthreads = min(cores, 64)			# the display stage has 64 column groups (cl.c:945-950)
-    o = Oracle(n_bins=bins)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    per = min(cores, 64)
+    inst = max(1, cores // 64)
     x = gaussian_iq(1024 * 1024, 7)
-    o.process(x, nthreads=nthreads)		# warm-up, page in
-    n = 0
+    oracles = [Oracle(n_bins=bins) for _ in range(inst)]
+    for o in oracles:
+        o.process(x, nthreads=per)		# warm-up, page in
+    counts = [0] * inst
     t0 = time.perf_counter()
-    while True:
-        o.process(x, nthreads=nthreads)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 4096:
-            break
-    return {"value": n * 1024 * 1024 / el / 1e6, "unit": "MSamples/s", "cores": nthreads, "kind": "port",
+
+    def work(i):				# (ctypes releases the GIL for the duration of the C call)
+        while time.perf_counter() - t0 < seconds and counts[i] < 4096:
+            oracles[i].process(x, nthreads=per)
+            counts[i] += 1
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(inst)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    el = time.perf_counter() - t0
+    n = sum(counts)
+    return {"value": n * 1024 * 1024 / el / 1e6, "unit": "MSamples/s", "cores": per * inst, "kind": "port",
+            "cores_online": cores,
             "sample": "%d batches of 1024 x 1024-pt spectra (%.1f s), oracle C restatement of fft.cl+display.cl, "
-                      "%d threads of %d host cores; the reference's own OpenCL path could not be run: no OpenCL CPU "
-                      "runtime (POCL) exists in this image and reference sources do not travel to the GPU box"
-                      % (n, el, nthreads, cores)}
+                      "%d instance(s) x %d threads = %d of %d online host cores; the reference's own OpenCL path could not "
+                      "be run: no OpenCL CPU runtime (POCL) exists in this image and reference sources do not travel to "
+                      "the GPU box" % (n, el, inst, per, per * inst, cores)}
 
 
 def main():
@@ -167,6 +182,7 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     kw = dict(n_bins=bins, max_spectra=F * spb, max_batches=F, fft_len_log=cfg["log2n"], iq_fp16=cfg["fp16"])
+    transport = None
     if mode == "batch":
         f = gr_fosphor_amd.Fosphor(stream=stream, **kw)
         sf = None
@@ -181,10 +197,13 @@ def main():
             return int(t_ok.item())
 
         # the library's own RCCL communicator, or -- on every rank together -- torch.distributed's all-reduces
-        sf, _ = agree_on_transport(lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, **kw),
-                                   lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", **kw),
-                                   world, all_reduce_min,
-                                   log=lambda m: sys.stderr.write("rank %d: %s\n" % (rank, m)))
+        # (two phases: what can fail on one rank alone -- binding RCCL, the instance -- is agreed on before any rank enters the
+        # collective part, the id hand-off and ncclCommInitRank)
+        sf, transport = agree_on_transport(lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, connect=False, **kw),
+                                           lambda: ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="torch", **kw),
+                                           world, all_reduce_min,
+                                           log=lambda m: sys.stderr.write("rank %d: %s\n" % (rank, m)),
+                                           connect=lambda o: o.connect())
         f = sf.f
         if not args.strict_ordering:
             f.set_input_ordering(False)
@@ -236,6 +255,8 @@ def main():
     elapsed = time.perf_counter() - t0
     busy = f.kernel_busy()
     ms, launches = f.kernel_times()
+    xchg_ms, xchg_n = f.exchange_time()		# hipEvents around the ncclGroup on the count/merge stream (native transport)
+    exchange_ranks = sf.exchange_ranks() if sf is not None else 1	# ncclCommCount of the library's communicator
 
     ms_all, n_all, iso, twin_ms = [0.0] * 3, [0] * 3, None, None
     if not args.no_extra_passes:
@@ -285,10 +306,18 @@ def main():
         except Exception:
             twin_ms = None
 
+    k1_busy_rank = busy[0] / max(1, launches[0])		# this rank's K1 union time per launch, ms
+    k1_busy_ranks = [k1_busy_rank]
+    xchg_ranks_all = [exchange_ranks]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        g = torch.zeros(world, 2, dtype=torch.float64, device="cuda")
+        g[rank, 0], g[rank, 1] = k1_busy_rank, float(exchange_ranks)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        k1_busy_ranks = [float(v) for v in g[:, 0].tolist()]
+        xchg_ranks_all = [int(v) for v in g[:, 1].tolist()]
 
     total_samples = world * args.steps * F * samples_per_batch
     value = total_samples / elapsed / 1e6
@@ -323,7 +352,11 @@ def main():
             if traffic:
                 break
         fused16 = os.environ.get("FOSPHOR_AMD_K1H_FUSED", "1")[:1] != "0"
-        k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)", 13: "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
+        # (the launch condition of launch_k1: k1w_fft_bin unless FOSPHOR_AMD_K1W=0 or the hop is odd)
+        k1w = os.environ.get("FOSPHOR_AMD_K1W", "1")[:1] != "0" and not (hop & 1)
+        k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)",
+                   13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, overlap reused from registers)" if k1w else
+                       "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
                    16: "k1h_fused (K1, both LDS stages in one kernel, intermediate in the XCD's L2)" if fused16 else
                        "k1h_stage_a + k1h_stage_b (K1, two LDS stages, two kernels)"}[cfg["log2n"]]
         if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
@@ -351,6 +384,15 @@ def main():
                 "input_ordering": "strict" if args.strict_ordering else "relaxed",
                 "strict_ordering_value": strict_value,	# MSamples/s of the same steps with the default (strict) ordering, untimed extra pass
                 "host_submit_fraction": t_submit / elapsed,
+                # multi-GPU self-description: what the exchange actually spanned, as the transport itself reports it
+                "transport": ("none" if (sf is None or not sf.active) else
+                              "native RCCL (library communicator)" if sf.exchange == "rccl" else "torch.distributed (%s)" % dist.get_backend()),
+                "transport_agreement": transport,
+                "exchange_ranks": exchange_ranks,			# ncclCommCount(library communicator) on rank 0 (1 = no exchange)
+                "exchange_ranks_per_rank": xchg_ranks_all,
+                "exchange_ms_per_frame": (xchg_ms / xchg_n) if xchg_n else None,	# hipEvents around the ncclGroup, rank 0
+                "exchanges_timed": xchg_n,
+                "k1_busy_ms_per_launch_per_rank": {"min": min(k1_busy_ranks), "max": max(k1_busy_ranks), "all": k1_busy_ranks},
                 "exchange": "none" if (sf is None or not sf.active) else
                             ("native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
                              "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else

@@ -92,6 +92,9 @@ SIGNATURES = {
     "fosphor_amd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "fosphor_amd_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     "fosphor_amd_comm_destroy": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_comm_available": (C.c_int, []),
+    "fosphor_amd_comm_count": (C.c_int, [C.c_void_p]),
+    "fosphor_amd_exchange_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "fosphor_amd_exchange": (C.c_int, [C.c_void_p, C.c_void_p]),
     "fosphor_amd_exchange_sliced": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "fosphor_amd_merge_sliced": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -141,6 +144,9 @@ SIGNATURES = {
     "fosphor_amd_sink_ui_action": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_sink_reshape": (None, [C.c_void_p, C.c_int, C.c_int]),
     "fosphor_amd_sink_mouse_action": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "fosphor_amd_sink_set_freq_callback": (None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fosphor_amd_sink_write_prepare": (C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "fosphor_amd_sink_write_commit": (None, [C.c_void_p, C.c_int]),
     "fosphor_amd_sink_get_render": (None, [C.c_void_p, C.c_int, C.POINTER(Render)]),
     "fosphor_amd_sink_set_frequency_range": (None, [C.c_void_p, C.c_double, C.c_double]),
     "fosphor_amd_sink_set_fft_window": (None, [C.c_void_p, C.c_void_p]),

@@ -210,6 +210,14 @@ class Fosphor:
     def wait_input(self):
         return self.L.fosphor_amd_wait_input(self.h)
 
+    def exchange_time(self):
+        """(ms summed over the exchanges recorded while profiling was on, how many); resets"""
+        ms, n = C.c_float(), C.c_int()
+        rv = self.L.fosphor_amd_exchange_time(self.h, C.byref(ms), C.byref(n))
+        if rv:
+            raise RuntimeError("fosphor_amd_exchange_time -> %d" % rv)
+        return ms.value, n.value
+
     def kernel_busy(self):
         """ms during which >= 1 kernel of each kind ran (call before kernel_times)"""
         ms = (C.c_float * 3)()

@@ -161,6 +161,8 @@ struct fosphor
 	std::vector<hipEvent_t> ev_pool;
 	std::vector<int> ev_kind;		/* kernel index per (start, stop) pair */
 	size_t ev_used;
+	std::vector<hipEvent_t> xev_pool;	/* (start, stop) pairs around the exchanges of the multi-GPU path, while profiling is on */
+	size_t xev_used;
 };
 
 /* ------------------------------------------------------------------------ */
@@ -292,6 +294,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 	if (self->h_thr) (void)hipHostFree(self->h_thr);
 	if (self->h_win) (void)hipHostFree(self->h_win);
 	for (hipEvent_t e : self->ev_pool) (void)hipEventDestroy(e);
+	for (hipEvent_t e : self->xev_pool) (void)hipEventDestroy(e);
 	if (self->own_stream && self->stream)
 		(void)hipStreamDestroy(self->stream);
 	delete self;
@@ -303,6 +306,8 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	int ndev = 0;
 	size_t tiles_max;
 	std::vector<float2> tw;
+	int cu_reserved = 0;
+	uint32_t cu_mask_fft[8], cu_mask_cnt[8];
 
 	if (!self)
 		return NULL;
@@ -361,10 +366,28 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		HIP_TRY(hipGetDevice(&self->device), "hipGetDevice");
 	}
 
-	if (cfg && cfg->stream) {
+	/* Measurement only (profiles/r04_ceiling.md): FOSPHOR_AMD_DBG_CUMASK=k reserves k CUs (k / 8 per XCD; mask bit i is CU i / 8 of
+	 * XCD i % 8, tools/ubench/cu_mask_probe.hip) for the count / merge streams and confines every FFT stream -- including the
+	 * instance's main stream, which is then the library's own and not the caller's -- to the rest.  Space-sharing by mask
+	 * measured far worse than the hardware's own interleaving; nothing in the product path sets it. */
+	{
+		const char *e = getenv("FOSPHOR_AMD_DBG_CUMASK");
+		cu_reserved = e ? atoi(e) : 0;
+		if (cu_reserved < 8 || cu_reserved > 128 || (cu_reserved & 7))
+			cu_reserved = 0;
+		for (int w = 0; w < 8; w++) {
+			const int lo = 32 * w, split = 256 - cu_reserved;
+			cu_mask_fft[w] = split >= lo + 32 ? ~0u : (split <= lo ? 0u : ((1u << (split - lo)) - 1u));
+			cu_mask_cnt[w] = ~cu_mask_fft[w];
+		}
+	}
+	if (cfg && cfg->stream && !cu_reserved) {
 		self->stream = (hipStream_t)cfg->stream;
 	} else {
-		HIP_TRY(hipStreamCreateWithFlags(&self->stream, hipStreamNonBlocking), "hipStreamCreate");
+		if (cu_reserved)
+			HIP_TRY(hipExtStreamCreateWithCUMask(&self->stream, 8, cu_mask_fft), "hipExtStreamCreateWithCUMask");
+		else
+			HIP_TRY(hipStreamCreateWithFlags(&self->stream, hipStreamNonBlocking), "hipStreamCreate");
 		self->own_stream = 1;
 	}
 
@@ -386,7 +409,10 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	self->k1_streams[0] = self->stream;
 	for (int i = 1; i < self->n_k1_streams; i++) {
-		HIP_TRY(hipStreamCreateWithFlags(&self->k1_streams[i], hipStreamNonBlocking), "hipStreamCreate (FFT stream)");
+		if (cu_reserved)
+			HIP_TRY(hipExtStreamCreateWithCUMask(&self->k1_streams[i], 8, cu_mask_fft), "hipExtStreamCreateWithCUMask (FFT stream)");
+		else
+			HIP_TRY(hipStreamCreateWithFlags(&self->k1_streams[i], hipStreamNonBlocking), "hipStreamCreate (FFT stream)");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1s_done[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
@@ -415,8 +441,13 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	}
 	/* host staging slot: the reference's cap of 1024 spectra per call (cl.c:885), or this instance's */
 	self->stage_samples = (size_t)self->n * (self->max_spectra < 1024 ? self->max_spectra : 1024);
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
-	HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	if (cu_reserved) {
+		HIP_TRY(hipExtStreamCreateWithCUMask(&self->stream2, 8, cu_mask_cnt), "hipExtStreamCreateWithCUMask (count stream)");
+		HIP_TRY(hipExtStreamCreateWithCUMask(&self->stream3, 8, cu_mask_cnt), "hipExtStreamCreateWithCUMask (merge stream)");
+	} else {
+		HIP_TRY(hipStreamCreateWithFlags(&self->stream2, hipStreamNonBlocking), "hipStreamCreate (count stream)");
+		HIP_TRY(hipStreamCreateWithFlags(&self->stream3, hipStreamNonBlocking), "hipStreamCreate (merge stream)");
+	}
 	for (int i = 0; i < 2; i++) {
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k2_done[i], dep_event_flags()), "create event");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
@@ -1554,6 +1585,60 @@ extern "C" int fosphor_amd_merge(struct fosphor *self, int total_batch)
 
 /* ---- native exchange (RCCL over xGMI), fosphor_exchange.cpp --------------- */
 
+/* 1 when the RCCL library can be bound in this process (no communicator, no collective: purely local) */
+extern "C" int fosphor_amd_comm_available(void)
+{
+	return xchg_available();
+}
+
+/* ncclCommCount of a communicator made by fosphor_amd_comm_init */
+extern "C" int fosphor_amd_comm_count(void *comm)
+{
+	return comm ? xchg_comm_count(comm) : -EINVAL;
+}
+
+/* events around an exchange on its stream, while profiling is on (fosphor_amd_exchange_time) */
+static void xprof_begin(struct fosphor *self, hipStream_t st)
+{
+	if (!self->prof)
+		return;
+	while (self->xev_used + 2 > self->xev_pool.size()) {
+		hipEvent_t e;
+		if (hipEventCreateWithFlags(&e, dep_event_flags() & ~hipEventDisableTiming) != hipSuccess)
+			return;
+		self->xev_pool.push_back(e);
+	}
+	(void)hipEventRecord(self->xev_pool[self->xev_used], st);
+}
+
+static void xprof_end(struct fosphor *self, hipStream_t st)
+{
+	if (!self->prof || self->xev_used + 2 > self->xev_pool.size())
+		return;
+	if (hipEventRecord(self->xev_pool[self->xev_used + 1], st) == hipSuccess)
+		self->xev_used += 2;
+}
+
+/* Sum of the durations of the exchanges recorded since the last call (hipEvents on the count/merge stream around the
+ * ncclGroup), and how many there were; resets.  0 exchanges when profiling was off. */
+extern "C" int fosphor_amd_exchange_time(struct fosphor *self, float *ms_total, int *count)
+{
+	if (!self || !ms_total || !count)
+		return -EINVAL;
+	if (sync_all(self))
+		return -EIO;
+	*ms_total = 0.0f; *count = 0;
+	for (size_t i = 0; i + 1 < self->xev_used; i += 2) {
+		float t = 0.0f;
+		if (hipEventElapsedTime(&t, self->xev_pool[i], self->xev_pool[i + 1]) == hipSuccess) {
+			*ms_total += t;
+			(*count)++;
+		}
+	}
+	self->xev_used = 0;
+	return 0;
+}
+
 extern "C" int fosphor_amd_comm_unique_id(void *id128)
 {
 	return id128 ? xchg_unique_id(id128) : -EINVAL;
@@ -1578,10 +1663,14 @@ extern "C" int fosphor_amd_exchange(struct fosphor *self, void *comm)
 	if (!self || !comm)
 		return -EINVAL;
 	const size_t cells = (size_t)self->n_bins * self->n;
-	return xchg_allreduce3(comm, self->overlap ? self->stream2 : self->stream,
-	                       self->d_hc + (size_t)self->slot * cells, cells,
-	                       self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
-	                       (size_t)self->n);
+	hipStream_t st = self->overlap ? self->stream2 : self->stream;
+	xprof_begin(self, st);
+	const int rv = xchg_allreduce3(comm, st,
+	                               self->d_hc + (size_t)self->slot * cells, cells,
+	                               self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
+	                               (size_t)self->n);
+	xprof_end(self, st);
+	return rv;
 }
 
 /* Frequency-sliced form for large states (128 MiB of counts at 65536 x 512): the counts are
@@ -1595,10 +1684,14 @@ extern "C" int fosphor_amd_exchange_sliced(struct fosphor *self, void *comm, int
 	const size_t cells = (size_t)self->n_bins * self->n;
 	if (cells % (size_t)world)
 		return -EINVAL;
-	return xchg_reduce_scatter(comm, self->overlap ? self->stream2 : self->stream,
-	                           self->d_hc + (size_t)self->slot * cells, cells, world, rank,
-	                           self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
-	                           (size_t)self->n);
+	hipStream_t st = self->overlap ? self->stream2 : self->stream;
+	xprof_begin(self, st);
+	const int rv = xchg_reduce_scatter(comm, st,
+	                                   self->d_hc + (size_t)self->slot * cells, cells, world, rank,
+	                                   self->d_live_sum + (size_t)self->slot * self->n, self->d_vmax + (size_t)self->slot * self->n,
+	                                   (size_t)self->n);
+	xprof_end(self, st);
+	return rv;
 }
 
 extern "C" int fosphor_amd_merge_sliced(struct fosphor *self, int total_batch, int world, int rank)

@@ -38,6 +38,7 @@ struct Rccl {
 	ncclResult_t (*GetUniqueId)(ncclUniqueId *);
 	ncclResult_t (*CommInitRank)(ncclComm_t *, int nranks, ncclUniqueId id, int rank);
 	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*CommCount)(const ncclComm_t, int *);
 	ncclResult_t (*GroupStart)(void);
 	ncclResult_t (*GroupEnd)(void);
 	ncclResult_t (*AllReduce)(const void *send, void *recv, size_t count, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
@@ -67,7 +68,7 @@ static Rccl *rccl(void)
 			BIND(GetUniqueId, "ncclGetUniqueId"); BIND(CommInitRank, "ncclCommInitRank");
 			BIND(CommDestroy, "ncclCommDestroy"); BIND(GroupStart, "ncclGroupStart"); BIND(GroupEnd, "ncclGroupEnd");
 			BIND(AllReduce, "ncclAllReduce"); BIND(ReduceScatter, "ncclReduceScatter");
-			BIND(AllGather, "ncclAllGather"); BIND(GetErrorString, "ncclGetErrorString");
+			BIND(AllGather, "ncclAllGather"); BIND(GetErrorString, "ncclGetErrorString"); BIND(CommCount, "ncclCommCount");
 #undef BIND
 			if (r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.AllReduce &&
 			    r.ReduceScatter && r.AllGather)
@@ -85,6 +86,23 @@ static int check(Rccl *r, ncclResult_t e, const char *what)
 		return 0;
 	fprintf(stderr, "[!] fosphor_amd: %s: %s\n", what, r->GetErrorString ? r->GetErrorString(e) : "RCCL error");
 	return -EIO;
+}
+
+int xchg_available(void)
+{
+	return rccl() ? 1 : 0;
+}
+
+/* ranks of the communicator as RCCL itself counts them */
+int xchg_comm_count(void *comm)
+{
+	Rccl *r = rccl();
+	int n = 0;
+	if (!r || !r->CommCount)
+		return -ENOSYS;
+	if (check(r, r->CommCount((ncclComm_t)comm, &n), "ncclCommCount"))
+		return -EIO;
+	return n;
 }
 
 int xchg_unique_id(void *id128)

@@ -141,6 +141,8 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
                            const K1Params &p, int force_exact, hipStream_t s);
 
 /* fosphor_exchange.cpp: RCCL bound at run time */
+int xchg_available(void);
+int xchg_comm_count(void *comm);
 int xchg_unique_id(void *id128);
 int xchg_comm_init(void **comm, int world, int rank, const void *id128);
 int xchg_comm_destroy(void *comm);

@@ -195,7 +195,9 @@ struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
  * pattern all of those order above every finite value, so one running v_max_u32 per spectrum
  * collects "some sample needs the exact path" without per-sample compares or branches. */
 #ifndef K1_DBG_EPI
-#define K1_DBG_EPI 0		/* measurement only (wrong results): 1 no v_log_f32, 2 no ambiguity measure, 4 no live / max update, 8 no bin byte */
+#define K1_DBG_EPI 0		/* measurement only (wrong results): 1 no v_log_f32, 2 no ambiguity measure, 4 no live / max update, 8 no bin byte,
+				 * 16 no bin-index stores, 32 sixteen LDS atomics per spectrum on a dummy counter array (what counting inside K1
+				 * would issue): the probe builds of profiles/r04_ceiling.md (tools/r04_ceiling_build.sh) */
 #endif
 static __device__ __forceinline__ float bin_fast(float re, float im, const BinConst &k, float *l2_out, uint32_t *amb_bits)
 {
@@ -268,6 +270,9 @@ void k1_fft_bin(const K1Params p)
 	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
 	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles, shared by the block */
 	__shared__ float win_tab[kN];			/* window, shared by the block */
+#if K1_DBG_EPI & 32
+	__shared__ uint32_t dbg_cnt[256 * 32];		/* probe: the counter image of a 64-column slab */
+#endif
 
 	const int lane   = threadIdx.x & 63;
 	const int wv     = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);	/* tile, spectrum index, row predicate: SGPRs */
@@ -493,6 +498,11 @@ void k1_fft_bin(const K1Params p)
 				asm("v_fma_f32 %0, %0, %1, %2" : "+v"(live[m]) : "s"(p.w), "v"(l2[m]));
 				vmax[m] = max_f32(vmax[m], l2[m]);		/* display.cl:139 */
 			}
+#if K1_DBG_EPI & 32
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				atomicAdd(&dbg_cnt[((pack[m] >> (8 * u)) & 0xffu) * 32 + (lane & 31)], (lane & 32) ? 0x10000u : 1u);
+#endif
 			if (t >= p.wf_first) {				/* uniform: one scalar branch */
 				float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * kN + lane;
 #pragma unroll
@@ -505,9 +515,18 @@ void k1_fft_bin(const K1Params p)
 		K1_STAMP(5);			/* 4th epilogue (the first three land in 7) */
 		/* 4 spectra x 1 column per dword, coalesced 256 B per instruction */
 		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
+		if (K1_DBG_EPI & 16) {
+			uint32_t any = 0;			/* keep the values alive without the stores */
 #pragma unroll
-		for (int m = 0; m < 16; m++)
-			dst[64 * m] = pack[m];
+			for (int m = 0; m < 16; m++)
+				any |= pack[m];
+			if (any == 0xdeadbeefu)
+				dst[0] = any;
+		} else {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				dst[64 * m] = pack[m];
+		}
 	}
 
 	/* leave the log2 domain: pwr = log10|X| = l2 * log10(2)/2; an untouched max is exactly -1000 */
@@ -1930,7 +1949,8 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			return hipErrorInvalidValue;
 		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); needs 16-byte aligned
 		 * windows (even hop).  FOSPHOR_AMD_K1W=0: the general kernel. */
-		static const bool k1w_on = [] { const char *e = getenv("FOSPHOR_AMD_K1W"); return !(e && *e == '0'); }();
+		const char *k1w_env = getenv("FOSPHOR_AMD_K1W");
+		const bool k1w_on = !(k1w_env && *k1w_env == '0');
 		if (k1w_on && !(p.hop & 1)) {
 			constexpr int ldsw = 2 * 8192 * 8 + 4096 * 8;	/* two slabs + the radix-2 twiddles: 160 KiB */
 			static bool attr_w = false;
@@ -2041,6 +2061,9 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
  * 72 us). */
 /* NW waves per work-group: 4 where the kernel has to fit beside K1 (8-bit indices, N = 1024); 16 for the
  * 16-bit-index geometries, whose grids are small (N/64 x chunks) and whose rows are latency-bound */
+#ifndef K2_DBG
+#define K2_DBG 0		/* measurement only (wrong counts): 1 no LDS atomics, 2 plain LDS stores instead (profiles/r04_ceiling.md) */
+#endif
 template <int NW, int IF>
 __global__ __launch_bounds__(64 * NW)
 void k2_count(const K2Params p)
@@ -2100,6 +2123,9 @@ void k2_count(const K2Params p)
 		const uint32_t *src = p.bins + (size_t)c * (p.chunk >> 2) * p.n + x0;
 		const uint32_t nq = p.chunk >> 2, n = p.n;
 		uint32_t q = wv;
+#if K2_DBG == 1
+		uint32_t dbg_acc = 0;
+#endif
 #pragma unroll 1
 		for (; q + NW * (IF - 1) < nq; q += NW * IF) {	/* independent loads in flight per thread */
 			uint32_t v[IF];
@@ -2108,12 +2134,24 @@ void k2_count(const K2Params p)
 				v[u] = src[(q + NW * u) * n + lane];
 #pragma unroll
 			for (int u = 0; u < IF; u++) {
+#if K2_DBG == 1		/* probe: the loads and the address arithmetic without the LDS atomics */
+				dbg_acc += ((v[u] & 0xff) * 32 + hcol) ^ (((v[u] >> 8) & 0xff) * 32 + hcol) ^ (((v[u] >> 16) & 0xff) * 32 + hcol) ^ ((v[u] >> 24) * 32 + hcol);
+#elif K2_DBG == 2	/* probe: plain LDS stores instead of atomics */
+				h[((v[u]      ) & 0xff) * 32 + hcol] = inc;
+				h[((v[u] >>  8) & 0xff) * 32 + hcol] = inc;
+				h[((v[u] >> 16) & 0xff) * 32 + hcol] = inc;
+				h[((v[u] >> 24)       ) * 32 + hcol] = inc;
+#else
 				atomicAdd(&h[((v[u]      ) & 0xff) * 32 + hcol], inc);
 				atomicAdd(&h[((v[u] >>  8) & 0xff) * 32 + hcol], inc);
 				atomicAdd(&h[((v[u] >> 16) & 0xff) * 32 + hcol], inc);
 				atomicAdd(&h[((v[u] >> 24)       ) * 32 + hcol], inc);
+#endif
 			}
 		}
+#if K2_DBG == 1
+		if (dbg_acc == 0xdeadbeefu) h[0] = dbg_acc;
+#endif
 #pragma unroll 1
 		for (; q < nq; q += NW) {
 			const uint32_t v = src[q * n + lane];

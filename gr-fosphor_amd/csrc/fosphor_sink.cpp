@@ -9,6 +9,8 @@
 
 #include <chrono>
 
+#include <immintrin.h>
+
 #include <hip/hip_runtime.h>
 
 #include "../../include/fosphor_amd_sink.h"
@@ -130,16 +132,14 @@ std::complex<float> *fifo::peek_at(int offset) const
 const int sink_runtime::k_db_per_div[5] = {1, 2, 5, 10, 20};		/* base_sink_c_impl.cc:48 */
 
 sink_runtime::sink_runtime(int fifo_length)
-  : d_fosphor(nullptr), d_width(1024), d_height(1024), d_freq_cb(nullptr), d_freq_user(nullptr),
+  : d_fosphor(nullptr), d_zoom_applied(false), d_freq_cb(nullptr), d_freq_user(nullptr),
     d_active(false), d_frozen(false), d_visible(true), d_draining(false),
-    d_pending(0), d_db_ref(0), d_db_per_div_idx(3),
-    d_zoom_enabled(false), d_zoom_center(0.5), d_zoom_width(0.2), d_ratio(0.35f),
+    d_pending(0),
     d_have_window(false), d_frames(0), d_samples(0),
     d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0),
-    d_copy_gen(0), d_copy_pending(0), d_copy_quit(false)
+    d_copy_gen(0), d_copy_pending(0), d_copy_sleepers(0), d_copy_quit(false)
 {
-	d_frequency.center = 0.0;
-	d_frequency.span = 1.0;
+	d_ui = ui_state{ 1024, 1024, 0, 3, false, 0.5, 0.2, 0.35f, 0.0, 1.0 };
 	d_fifo = new fifo(fifo_length, true);				/* base_sink_c_impl.cc:58 */
 	d_render_main = new fosphor_render();
 	fosphor_render_defaults(d_render_main);				/* :61-62 */
@@ -148,10 +148,8 @@ sink_runtime::sink_runtime(int fifo_length)
 	d_render_zoom->options &= ~(FRO_LABEL_PWR | FRO_LABEL_TIME);
 	for (int i = 0; i < kMaxInflight; i++)
 		d_events[i] = nullptr;
-	for (int i = 0; i < kCopyHelpers; i++) {
-		d_copy_jobs[i].gen = 0;
+	for (int i = 0; i < kCopyHelpers; i++)
 		d_copy_threads[i] = std::thread(&sink_runtime::copy_helper, this, i);
-	}
 }
 
 sink_runtime::~sink_runtime()
@@ -159,7 +157,7 @@ sink_runtime::~sink_runtime()
 	stop();
 	{
 		std::lock_guard<std::mutex> lock(d_copy_mutex);
-		d_copy_quit = true;
+		d_copy_quit.store(true);
 	}
 	d_copy_cv.notify_all();
 	for (int i = 0; i < kCopyHelpers; i++)
@@ -172,25 +170,69 @@ sink_runtime::~sink_runtime()
 	delete d_fifo;
 }
 
+/* Host copy into the pinned ring with non-temporal stores: the destination is read next by the DMA engine, so the lines
+ * need not be fetched for ownership nor kept in the core's caches (a third less memory traffic than memcpy's plain
+ * stores, and the source stays cached).  32-byte AVX stores where the CPU has them, memcpy otherwise. */
+__attribute__((target("avx")))
+static void stream_copy_avx(void *dst, const void *src, size_t bytes)
+{
+	char *d = (char *)dst;
+	const char *s = (const char *)src;
+	const size_t head = (32 - ((uintptr_t)d & 31)) & 31;
+	if (bytes < 256 || head > bytes) {
+		memcpy(d, s, bytes);
+		return;
+	}
+	memcpy(d, s, head);
+	d += head; s += head; bytes -= head;
+	size_t i = 0;
+	for (; i + 128 <= bytes; i += 128) {
+		const __m256i a = _mm256_loadu_si256((const __m256i *)(s + i));
+		const __m256i b = _mm256_loadu_si256((const __m256i *)(s + i + 32));
+		const __m256i c = _mm256_loadu_si256((const __m256i *)(s + i + 64));
+		const __m256i e = _mm256_loadu_si256((const __m256i *)(s + i + 96));
+		_mm256_stream_si256((__m256i *)(d + i), a);
+		_mm256_stream_si256((__m256i *)(d + i + 32), b);
+		_mm256_stream_si256((__m256i *)(d + i + 64), c);
+		_mm256_stream_si256((__m256i *)(d + i + 96), e);
+	}
+	_mm_sfence();
+	memcpy(d + i, s + i, bytes - i);
+}
+
+static void stream_copy(void *dst, const void *src, size_t bytes)
+{
+	static const bool have_avx = __builtin_cpu_supports("avx");
+	if (have_avx)
+		stream_copy_avx(dst, src, bytes);
+	else
+		memcpy(dst, src, bytes);
+}
+
 void sink_runtime::copy_helper(int idx)
 {
 	int seen = 0;
 	for (;;) {
-		copy_job job;
-		{
-			std::unique_lock<std::mutex> lock(d_copy_mutex);
-			d_copy_cv.wait(lock, [&] { return d_copy_quit || d_copy_jobs[idx].gen != seen; });
-			if (d_copy_quit)
-				return;
-			job = d_copy_jobs[idx];
-			seen = job.gen;
+		/* poll for the next generation for ~50 us (a streaming producer is back within that), then sleep */
+		const auto t_idle = std::chrono::steady_clock::now();
+		int spins = 0;
+		while (d_copy_gen.load(std::memory_order_acquire) == seen && !d_copy_quit.load(std::memory_order_relaxed)) {
+			_mm_pause();
+			if ((++spins & 255) == 0 &&
+			    std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(50)) {
+				std::unique_lock<std::mutex> lock(d_copy_mutex);
+				d_copy_sleepers.fetch_add(1, std::memory_order_seq_cst);
+				d_copy_cv.wait(lock, [&] { return d_copy_quit.load() || d_copy_gen.load(std::memory_order_acquire) != seen; });
+				d_copy_sleepers.fetch_sub(1, std::memory_order_seq_cst);
+			}
 		}
-		memcpy(job.dst, job.src, sizeof(std::complex<float>) * job.n);
-		{
-			std::lock_guard<std::mutex> lock(d_copy_mutex);
-			d_copy_pending--;
-		}
-		d_copy_done_cv.notify_one();
+		if (d_copy_quit.load())
+			return;
+		seen = d_copy_gen.load(std::memory_order_acquire);
+		const copy_job job = d_copy_jobs[idx];		/* written before the generation was published */
+		if (job.n)
+			stream_copy(job.dst, job.src, sizeof(std::complex<float>) * job.n);
+		d_copy_pending.fetch_sub(1, std::memory_order_acq_rel);
 	}
 }
 
@@ -233,41 +275,51 @@ split split_window(int width, bool zoom)
 }
 }
 
-void sink_runtime::layout_panes()
+void sink_runtime::layout_panes(const ui_state &ui)
 {
-	const split sp = split_window(d_width, d_zoom_enabled);
+	const split sp = split_window(ui.width, ui.zoom_enabled);
 	std::lock_guard<std::mutex> lk(d_render_mutex);
 	struct fosphor_render *both[2] = { d_render_main, d_render_zoom };
 
 	d_render_main->width = sp.main.width;
 	d_render_main->options = (d_render_main->options | sp.main_set) & ~sp.main_clear;
-	if (d_zoom_enabled) {				/* the zoom pane keeps its last geometry while it is hidden */
+	if (ui.zoom_enabled) {				/* the zoom pane keeps its last geometry while it is hidden */
 		d_render_zoom->pos_x = sp.zoom.pos_x;
 		d_render_zoom->width = sp.zoom.width;
 	}
 	struct fosphor_channel &ch = d_render_main->channels[0];
-	ch.enabled = d_zoom_enabled;
-	ch.center  = (float)d_zoom_center;
-	ch.width   = (float)d_zoom_width;
+	ch.enabled = ui.zoom_enabled;
+	ch.center  = (float)ui.zoom_center;
+	ch.width   = (float)ui.zoom_width;
 	d_render_zoom->freq_center = ch.center;
 	d_render_zoom->freq_span   = ch.width;
 	for (struct fosphor_render *r : both) {
-		r->height = d_height;
-		r->histo_wf_ratio = d_ratio;
+		r->height = ui.height;
+		r->histo_wf_ratio = ui.ratio;
 		fosphor_render_refresh(r);
 	}
+	d_zoom_applied = ui.zoom_enabled;
 }
 
 void sink_runtime::settings_apply(uint32_t s)				/* :220-288, compute-relevant part */
 {
+	if (!s)
+		return;
+	const ui_state ui = ui_snapshot();				/* one consistent copy for the whole pass */
 	if (s & SETTING_POWER_RANGE)
-		fosphor_set_power_range(d_fosphor, d_db_ref, k_db_per_div[d_db_per_div_idx]);
+		fosphor_set_power_range(d_fosphor, ui.db_ref, k_db_per_div[ui.db_per_div_idx]);
 	if (s & SETTING_FREQUENCY_RANGE)
-		fosphor_set_frequency_range(d_fosphor, d_frequency.center, d_frequency.span);
-	if ((s & SETTING_FFT_WINDOW) && d_have_window)
-		fosphor_set_fft_window(d_fosphor, d_fft_window);
+		fosphor_set_frequency_range(d_fosphor, ui.freq_center, ui.freq_span);
+	if ((s & SETTING_FFT_WINDOW) && d_have_window) {
+		float win[1024];
+		{
+			std::lock_guard<std::mutex> lk(d_ui_mutex);
+			memcpy(win, d_fft_window, sizeof(win));
+		}
+		fosphor_set_fft_window(d_fosphor, win);
+	}
 	if (s & (SETTING_DIMENSIONS | SETTING_RENDER_OPTIONS))
-		layout_panes();
+		layout_panes(ui);
 }
 
 struct fosphor_render sink_runtime::render_copy(bool zoom) const
@@ -278,29 +330,39 @@ struct fosphor_render sink_runtime::render_copy(bool zoom) const
 
 void sink_runtime::reshape(int width, int height)			/* :291-296 */
 {
-	d_width = width;
-	d_height = height;
+	{
+		std::lock_guard<std::mutex> lk(d_ui_mutex);
+		d_ui.width = width;
+		d_ui.height = height;
+	}
 	settings_mark_changed(SETTING_DIMENSIONS);
 }
 
 bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, double *freq)	/* :371-397 */
 {
-	std::lock_guard<std::mutex> lk(d_render_mutex);	/* the worker re-lays the panes and owns d_fosphor's lifetime */
-	if (action != CLICK || !d_fosphor)
+	if (action != CLICK)
 		return false;
-	const int in_main = fosphor_render_pos_inside(d_render_main, x, y);
-	const int in_zoom = d_zoom_enabled ? fosphor_render_pos_inside(d_render_zoom, x, y) : 0;
 	double f;
-	if (in_main & 1)
-		f = fosphor_pos2freq(d_fosphor, d_render_main, x);
-	else if (in_zoom & 1)
-		f = fosphor_pos2freq(d_fosphor, d_render_zoom, x);
-	else
-		return false;
+	{
+		/* the worker re-lays the panes and owns d_fosphor's lifetime: the position is mapped under the render lock ... */
+		std::lock_guard<std::mutex> lk(d_render_mutex);
+		if (!d_fosphor)
+			return false;
+		const int in_main = fosphor_render_pos_inside(d_render_main, x, y);
+		const int in_zoom = d_render_main->channels[0].enabled ? fosphor_render_pos_inside(d_render_zoom, x, y) : 0;
+		if (in_main & 1)
+			f = fosphor_pos2freq(d_fosphor, d_render_main, x);
+		else if (in_zoom & 1)
+			f = fosphor_pos2freq(d_fosphor, d_render_zoom, x);
+		else
+			return false;
+	}
+	/* ... and published WITHOUT it, like the reference's message_port_pub (:385,390): a callback may re-enter the sink
+	 * (get_render, another mouse action) or take its time without stalling the worker */
 	if (freq)
 		*freq = f;
 	if (d_freq_cb)
-		d_freq_cb(f, d_freq_user);					/* the "freq" message of :385,390 */
+		d_freq_cb(f, d_freq_user);
 	return true;
 }
 
@@ -379,7 +441,7 @@ void sink_runtime::render()						/* :130-201 */
 
 	if (d_visible) {
 		fosphor_draw(d_fosphor, d_render_main);			/* :178-195: the per-frame sync point */
-		if (d_zoom_enabled)
+		if (d_zoom_applied)
 			fosphor_draw(d_fosphor, d_render_zoom);		/* :189-190 */
 		d_frames++;
 		retire_uploads(true);
@@ -410,26 +472,46 @@ int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432
 	if (l >= 128 * 1024) {
 		/* one core copies ~12 GB/s; the link behind the FIFO carries 4-5 times that */
 		const size_t part = ((size_t)l / (kCopyHelpers + 1)) & ~(size_t)1023;
-		{
-			std::lock_guard<std::mutex> lock(d_copy_mutex);
-			d_copy_gen++;
-			for (int k = 0; k < kCopyHelpers; k++) {
-				d_copy_jobs[k].dst = dst + part * (k + 1);
-				d_copy_jobs[k].src = in + part * (k + 1);
-				d_copy_jobs[k].n = (k == kCopyHelpers - 1) ? (size_t)l - part * kCopyHelpers : part;
-				d_copy_jobs[k].gen = d_copy_gen;
-			}
-			d_copy_pending = kCopyHelpers;
+		for (int k = 0; k < kCopyHelpers; k++) {
+			d_copy_jobs[k].dst = dst + part * (k + 1);
+			d_copy_jobs[k].src = in + part * (k + 1);
+			d_copy_jobs[k].n = (k == kCopyHelpers - 1) ? (size_t)l - part * kCopyHelpers : part;
 		}
-		d_copy_cv.notify_all();
-		memcpy(dst, in, sizeof(std::complex<float>) * part);
-		std::unique_lock<std::mutex> lock(d_copy_mutex);
-		d_copy_done_cv.wait(lock, [&] { return d_copy_pending == 0; });
+		d_copy_pending.store(kCopyHelpers, std::memory_order_relaxed);
+		d_copy_gen.fetch_add(1, std::memory_order_seq_cst);		/* publishes the jobs */
+		if (d_copy_sleepers.load(std::memory_order_seq_cst)) {
+			{ std::lock_guard<std::mutex> lock(d_copy_mutex); }	/* a helper between its check and its wait has the mutex */
+			d_copy_cv.notify_all();
+		}
+		stream_copy(dst, in, sizeof(std::complex<float>) * part);
+		while (d_copy_pending.load(std::memory_order_acquire))
+			_mm_pause();
 	} else {
 		memcpy(dst, in, sizeof(std::complex<float>) * (size_t)l);
 	}
 	d_fifo->write_commit(l);
 	return l;
+}
+
+std::complex<float> *sink_runtime::write_prepare(int want, int *got, int timeout_ms)
+{
+	*got = 0;
+	int l = want;
+	const int mw = d_fifo->write_max_size();			/* contiguous room up to the end of the ring */
+	if (l > mw)
+		l = mw;
+	if (l <= 0 || !d_active)
+		return nullptr;
+	std::complex<float> *dst = d_fifo->write_prepare_for(l, timeout_ms);
+	if (dst)
+		*got = l;
+	return dst;
+}
+
+void sink_runtime::write_commit(int n)
+{
+	if (n > 0)
+		d_fifo->write_commit(n);
 }
 
 bool sink_runtime::start()						/* :464-472 */
@@ -456,42 +538,49 @@ bool sink_runtime::stop()						/* :474-483 */
 
 void sink_runtime::execute_ui_action(ui_action_t action)		/* :305-369 */
 {
-	switch (action) {
-	case DB_PER_DIV_UP:	if (d_db_per_div_idx < 4) d_db_per_div_idx++; break;
-	case DB_PER_DIV_DOWN:	if (d_db_per_div_idx > 0) d_db_per_div_idx--; break;
-	case REF_UP:		d_db_ref += k_db_per_div[d_db_per_div_idx]; break;
-	case REF_DOWN:		d_db_ref -= k_db_per_div[d_db_per_div_idx]; break;
-	case ZOOM_TOGGLE:	d_zoom_enabled = !d_zoom_enabled; break;
-	case ZOOM_WIDTH_UP:	if (d_zoom_enabled) d_zoom_width *= 2.0; break;
-	case ZOOM_WIDTH_DOWN:	if (d_zoom_enabled) d_zoom_width /= 2.0; break;
-	case ZOOM_CENTER_UP:	if (d_zoom_enabled) d_zoom_center += d_zoom_width / 8.0; break;
-	case ZOOM_CENTER_DOWN:	if (d_zoom_enabled) d_zoom_center -= d_zoom_width / 8.0; break;
-	case RATIO_UP:		if (d_ratio < 0.8f) d_ratio += 0.05f; break;
-	case RATIO_DOWN:	if (d_ratio > 0.2f) d_ratio -= 0.05f; break;
-	case FREEZE_TOGGLE:	d_frozen = !d_frozen; break;
+	{
+		std::lock_guard<std::mutex> lk(d_ui_mutex);
+		ui_state &u = d_ui;
+		switch (action) {
+		case DB_PER_DIV_UP:	if (u.db_per_div_idx < 4) u.db_per_div_idx++; break;
+		case DB_PER_DIV_DOWN:	if (u.db_per_div_idx > 0) u.db_per_div_idx--; break;
+		case REF_UP:		u.db_ref += k_db_per_div[u.db_per_div_idx]; break;
+		case REF_DOWN:		u.db_ref -= k_db_per_div[u.db_per_div_idx]; break;
+		case ZOOM_TOGGLE:	u.zoom_enabled = !u.zoom_enabled; break;
+		case ZOOM_WIDTH_UP:	if (u.zoom_enabled) u.zoom_width *= 2.0; break;
+		case ZOOM_WIDTH_DOWN:	if (u.zoom_enabled) u.zoom_width /= 2.0; break;
+		case ZOOM_CENTER_UP:	if (u.zoom_enabled) u.zoom_center += u.zoom_width / 8.0; break;
+		case ZOOM_CENTER_DOWN:	if (u.zoom_enabled) u.zoom_center -= u.zoom_width / 8.0; break;
+		case RATIO_UP:		if (u.ratio < 0.8f) u.ratio += 0.05f; break;
+		case RATIO_DOWN:	if (u.ratio > 0.2f) u.ratio -= 0.05f; break;
+		case FREEZE_TOGGLE:	d_frozen = !d_frozen; break;
+		}
 	}
 	settings_mark_changed(SETTING_POWER_RANGE | SETTING_RENDER_OPTIONS);
 }
 
 void sink_runtime::set_frequency_range(double center, double span)
 {
-	d_frequency.center = center; d_frequency.span = span;
+	{ std::lock_guard<std::mutex> lk(d_ui_mutex); d_ui.freq_center = center; d_ui.freq_span = span; }
 	settings_mark_changed(SETTING_FREQUENCY_RANGE);
 }
 void sink_runtime::set_frequency_center(double center)
 {
-	d_frequency.center = center;
+	{ std::lock_guard<std::mutex> lk(d_ui_mutex); d_ui.freq_center = center; }
 	settings_mark_changed(SETTING_FREQUENCY_RANGE);
 }
 void sink_runtime::set_frequency_span(double span)
 {
-	d_frequency.span = span;
+	{ std::lock_guard<std::mutex> lk(d_ui_mutex); d_ui.freq_span = span; }
 	settings_mark_changed(SETTING_FREQUENCY_RANGE);
 }
 void sink_runtime::set_fft_window(const float *win)
 {
-	memcpy(d_fft_window, win, sizeof(d_fft_window));
-	d_have_window = true;
+	{
+		std::lock_guard<std::mutex> lk(d_ui_mutex);
+		memcpy(d_fft_window, win, sizeof(d_fft_window));
+		d_have_window = true;
+	}
 	settings_mark_changed(SETTING_FFT_WINDOW);
 }
 void sink_runtime::set_visible(bool visible) { d_visible = visible; }
@@ -585,6 +674,10 @@ int   fosphor_amd_sink_mouse_action(fosphor_amd_sink *s, int action, int x, int 
 {
 	return s->s.execute_mouse_action((sink_runtime::mouse_action_t)action, x, y, freq) ? 1 : 0;
 }
+void  fosphor_amd_sink_set_freq_callback(fosphor_amd_sink *s, void (*cb)(double, void *), void *user)
+{
+	s->s.set_freq_callback(cb, user);
+}
 void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_render *out)
 {
 	*out = s->s.render_copy(zoom != 0);
@@ -592,6 +685,14 @@ void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_
 void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double c, double sp) { s->s.set_frequency_range(c, sp); }
 void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win) { s->s.set_fft_window(win); }
 void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int v) { s->s.set_visible(v != 0); }
+void *fosphor_amd_sink_write_prepare(fosphor_amd_sink *s, int want, int *got, int timeout_ms)
+{
+	int g = 0;
+	void *p = s->s.write_prepare(want, &g, timeout_ms);
+	if (got) *got = g;
+	return p;
+}
+void  fosphor_amd_sink_write_commit(fosphor_amd_sink *s, int n) { s->s.write_commit(n); }
 struct fosphor *fosphor_amd_sink_core(fosphor_amd_sink *s) { return s->s.core(); }
 void  fosphor_amd_sink_stats(fosphor_amd_sink *s, uint64_t *frames, uint64_t *samples, int *db_ref, int *db_per_div, int *frozen)
 {

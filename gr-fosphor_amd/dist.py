@@ -73,6 +73,11 @@ class NativeComm:
     """The library's own RCCL communicator (fosphor_amd_comm_*).  `broadcast_id(id_bytes_or_None) -> bytes`
     hands rank 0's 128-byte id to every rank; by default torch.distributed does it (any backend)."""
 
+    @staticmethod
+    def available(lib):
+        """True when the RCCL library can be bound in this process.  Purely local: no collective, no communicator."""
+        return int(lib.fosphor_amd_comm_available()) == 1
+
     def __init__(self, lib, rank, world, broadcast_id=None):
         self.L, self.rank, self.world = lib, rank, world
         buf = (C.c_char * 128)()
@@ -93,6 +98,10 @@ class NativeComm:
         box = [ident]
         dist.broadcast_object_list(box, src=0)
         return box[0]
+
+    def count(self):
+        """ncclCommCount of the communicator: how many ranks RCCL itself says it spans."""
+        return int(self.L.fosphor_amd_comm_count(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -120,10 +129,13 @@ class ShardedFosphor:
                         exchange of frame k is left in flight while frame k+1 is submitted (two slots).
     sliced: reduce-scatter + frequency-sliced merge (rccl only); default for states of 16 MiB and more.
     force_exchange: run the collectives on a single rank too (smoke test of the RCCL path).
+    connect=False: do everything that can fail on this rank ALONE (bind RCCL, construct the instance) and leave the
+                collective part -- rank 0's id to every rank, ncclCommInitRank -- to connect(): agree_on_transport puts
+                an agreement between the two, so that a rank whose local part failed leaves nobody waiting in a collective.
     """
 
     def __init__(self, fosphor_cls, rank, world, group=None, exchange=None, sliced=None, force_exchange=False,
-                 comm=None, **kw):
+                 comm=None, connect=True, **kw):
         import os
         import torch
         self.torch = torch
@@ -142,9 +154,13 @@ class ShardedFosphor:
         self.sliced = (cells * 4 >= (16 << 20)) if sliced is None else bool(sliced)
         if cells % world:
             self.sliced = False
-        self.comm = None
+        self.comm = comm
         if self.active and exchange == "rccl":
-            self.comm = comm or NativeComm(self.f.L, rank, world)
+            if comm is None and not NativeComm.available(self.f.L):
+                self.f.close()
+                raise RuntimeError("no RCCL library can be bound in this process")
+            if comm is None and connect:
+                self.connect()
         else:
             self.sliced = False
         # "torch" transport: K2 / all-reduce / K3 live on the library's second stream
@@ -160,6 +176,20 @@ class ShardedFosphor:
         self.f.set_partial_slot(0)
         self.k = 0
         self.pending = None		# torch transport: (works, slot, total_batch)
+
+    def connect(self, broadcast_id=None):
+        """The collective part of the native transport (every rank calls it, or none)."""
+        if self.active and self.exchange == "rccl" and self.comm is None:
+            self.comm = NativeComm(self.f.L, self.rank, self.world, broadcast_id)
+
+    def exchange_ranks(self):
+        """Ranks the exchange spans, as the transport itself reports it (ncclCommCount / the process group's size)."""
+        if not self.active:
+            return 1
+        if self.comm is not None:
+            return self.comm.count()
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     # ---- torch transport --------------------------------------------------------
     def _retire(self):
@@ -239,20 +269,40 @@ class ShardedFosphor:
         self.f.close()
 
 
-def agree_on_transport(build_native, build_fallback, world, all_reduce_min, log=None):
-    """Every rank must exchange through the same transport.  Each rank tries build_native() (the library's own RCCL
-    communicator); the ranks agree with one MIN all-reduce of "it worked here"; unless it worked everywhere, every rank --
-    including those whose native set-up succeeded, which is closed again -- builds build_fallback() instead.
+def agree_on_transport(build_native, build_fallback, world, all_reduce_min, log=None, connect=None):
+    """Every rank must exchange through the same transport.
+
+    Two phases when `connect` is given (what bench.py and ShardedFosphor(connect=False) use):
+      1. build_native() does ONLY what can fail on one rank alone -- bind the RCCL library, construct the instance --
+         and contains no collective; one MIN all-reduce of "it worked here" follows.  A rank whose RCCL cannot be
+         loaded, or whose instance fails to initialise, therefore never leaves the others waiting in the id broadcast
+         or in ncclCommInitRank: unless phase 1 worked everywhere, every rank builds build_fallback() instead.
+      2. connect(obj) is the collective part (rank 0's id to every rank, ncclCommInitRank), entered by every rank or
+         by none; a second MIN all-reduce catches a failure that every rank sees (rank 0 has no id, RCCL refuses the
+         topology).  A rank that dies INSIDE the collective can still stall the others: that is RCCL's own failure
+         mode and is left to its time-outs (NCCL_TIMEOUT / the launcher's).
+    Without `connect`, build_native() is the whole set-up (it may contain collectives; only failures that happen before
+    them, or on every rank alike, are caught).
     all_reduce_min(int) -> int is the caller's collective (torch.distributed on any backend).  Nothing here touches a GPU or
     re-executes anything: it can run before or after the first HIP call.  Returns (object, "native" | "fallback")."""
+    def agreed(flag):
+        return int(all_reduce_min(flag)) if world > 1 else flag
+
     try:
         obj, ok = build_native(), 1
     except Exception as e:
         if log:
             log("native exchange unavailable on this rank (%s)" % e)
         obj, ok = None, 0
-    if world > 1:
-        ok = int(all_reduce_min(ok))
+    ok = agreed(ok)
+    if ok and connect is not None:
+        try:
+            connect(obj)
+        except Exception as e:
+            if log:
+                log("native communicator could not be set up (%s)" % e)
+            ok = 0
+        ok = agreed(ok)
     if ok:
         return obj, "native"
     if obj is not None:

@@ -167,6 +167,14 @@ int fosphor_amd_comm_unique_id(void *id128);
 int fosphor_amd_comm_init(void **comm, int world, int rank, const void *id128);	/* on the current HIP device */
 int fosphor_amd_comm_destroy(void *comm);
 int fosphor_amd_exchange(struct fosphor *self, void *comm);
+/* 1 when an RCCL library can be bound in this process, else 0.  Purely local (no communicator, no collective):
+ * ranks agree on it BEFORE any of them enters the id hand-off or ncclCommInitRank. */
+int fosphor_amd_comm_available(void);
+/* ncclCommCount of a communicator made by fosphor_amd_comm_init: the ranks RCCL itself says it spans (< 0: error) */
+int fosphor_amd_comm_count(void *comm);
+/* While fosphor_amd_profile() is on, every exchange is bracketed by hipEvents on the stream it runs on: sum of their
+ * durations in ms and their number since the last call (resets; waits for the instance's streams). */
+int fosphor_amd_exchange_time(struct fosphor *self, float *ms_total, int *count);
 
 /* Frequency-sliced form for large states (65536 x 512: 128 MiB of counts): the counts are reduce-scattered,
  * rank r owning cells [r C / world, (r + 1) C / world) of the [bin][x] arrays (C = n_bins * N must divide), and

@@ -123,8 +123,8 @@ class sink_runtime
 	struct fosphor *core() { return d_fosphor; }
 	uint64_t frames() const { return d_frames.load(); }
 	uint64_t samples_processed() const { return d_samples.load(); }
-	int db_ref() const { return d_db_ref; }
-	int db_per_div() const { return k_db_per_div[d_db_per_div_idx]; }
+	int db_ref() const { return ui_snapshot().db_ref; }
+	int db_per_div() const { return k_db_per_div[ui_snapshot().db_per_div_idx]; }
 	bool frozen() const { return d_frozen.load(); }
 
  private:
@@ -141,21 +141,29 @@ class sink_runtime
 	void settings_mark_changed(uint32_t s) { d_pending.fetch_or(s, std::memory_order_acq_rel); }		/* base_sink_c_impl.cc:204-209 */
 	uint32_t settings_get_and_reset_changed() { return d_pending.exchange(0, std::memory_order_acq_rel); }	/* :211-218 */
 	void settings_apply(uint32_t s);
-	void layout_panes();
+	/* everything the UI thread writes and the worker reads, as one value: the worker takes ONE copy per settings pass
+	 * under d_ui_mutex and uses only that copy (a ZOOM_TOGGLE between two reads of the live fields would otherwise give
+	 * a mixed layout) */
+	struct ui_state {
+		int width, height, db_ref, db_per_div_idx;
+		bool zoom_enabled; double zoom_center, zoom_width; float ratio;
+		double freq_center, freq_span;
+	};
+	ui_state ui_snapshot() const { std::lock_guard<std::mutex> lk(d_ui_mutex); return d_ui; }
+	void layout_panes(const ui_state &ui);
 
 	fifo *d_fifo;
 	struct fosphor *d_fosphor;
 	struct fosphor_render *d_render_main, *d_render_zoom;	/* :61-66 */
-	int d_width, d_height;
+	ui_state d_ui;					/* written by the UI thread, under d_ui_mutex */
+	mutable std::mutex d_ui_mutex;
+	bool d_zoom_applied;				/* worker only: the zoom flag of the layout it last applied */
 	void (*d_freq_cb)(double, void *);
 	void *d_freq_user;
 	std::thread d_worker;
 	std::atomic<bool> d_active, d_frozen, d_visible, d_draining;
 	std::atomic<uint32_t> d_pending;		/* SETTING_* bits waiting for the worker */
 	mutable std::mutex d_render_mutex;		/* the two pane layouts + d_fosphor: worker vs. UI thread (the reference's d_render_mutex) */
-	int d_db_ref, d_db_per_div_idx;
-	bool d_zoom_enabled; double d_zoom_center, d_zoom_width; float d_ratio;
-	struct { double center, span; } d_frequency;
 	float d_fft_window[1024]; bool d_have_window;
 	std::atomic<uint64_t> d_frames, d_samples;
 
@@ -165,15 +173,27 @@ class sink_runtime
 	int d_inflight_head, d_inflight_n, d_inflight_samples;
 	void *d_events[kMaxInflight];
 
-	/* helper threads for large copies in work() */
-	enum { kCopyHelpers = 3 };
-	struct copy_job { std::complex<float> *dst; const std::complex<float> *src; size_t n; int gen; };
+	/* Helper threads for large copies in work().  The link behind the FIFO carries ~63 GB/s (PCIe Gen5 x16), one core
+	 * copies ~12: a 1 Mi-sample work() call is cut into kCopyHelpers + 1 pieces written with non-temporal stores
+	 * (the ring is read next by the DMA engine, not by a core).  Hand-off: a generation counter the helpers poll
+	 * for a few tens of microseconds after each job -- a streaming producer calls work() back to back, and a
+	 * condition-variable wake-up costs as much as a helper's whole share of the copy -- before they go to sleep. */
+	enum { kCopyHelpers = 7 };
+	struct copy_job { std::complex<float> *dst; const std::complex<float> *src; size_t n; };
 	std::thread d_copy_threads[kCopyHelpers];
 	copy_job d_copy_jobs[kCopyHelpers];
 	std::mutex d_copy_mutex;
-	std::condition_variable d_copy_cv, d_copy_done_cv;
-	int d_copy_gen, d_copy_pending;
-	bool d_copy_quit;
+	std::condition_variable d_copy_cv;
+	std::atomic<int> d_copy_gen, d_copy_pending, d_copy_sleepers;
+	std::atomic<bool> d_copy_quit;
+
+ public:
+	/* Zero-copy producer interface: a source that can write its samples anywhere (an SDR driver's receive call, a file
+	 * read) fills the pinned ring itself and the host copy of work() disappears.  write_prepare returns room for up
+	 * to `want` contiguous samples (*got of them; NULL when the sink is not running or nothing frees up within
+	 * timeout_ms), write_commit hands `n <= *got` of them to the worker.  Single producer, like work(). */
+	std::complex<float> *write_prepare(int want, int *got, int timeout_ms);
+	void write_commit(int n);
 };
 
 } // namespace fosphor_amd
@@ -220,11 +240,20 @@ void  fosphor_amd_sink_ui_action(fosphor_amd_sink *s, int action);
  * 1 and *freq = the frequency under the cursor when (x, y) lies in the main or the zoom pane, else 0. */
 void  fosphor_amd_sink_reshape(fosphor_amd_sink *s, int width, int height);
 int   fosphor_amd_sink_mouse_action(fosphor_amd_sink *s, int action, int x, int y, double *freq);
+/* where the reference publishes the clicked frequency on the block's "freq" message port (base_sink_c_impl.cc:385,390) this
+ * runtime calls `cb(freq, user)` -- on the thread that reported the click, with no lock of the sink held: the callback may
+ * call back into the sink (get_render, mouse_action ...).  cb = NULL removes it. */
+void  fosphor_amd_sink_set_freq_callback(fosphor_amd_sink *s, void (*cb)(double freq, void *user), void *user);
 /* copies of the two pane layouts (main, zoom) as the runtime maintains them */
 void  fosphor_amd_sink_get_render(fosphor_amd_sink *s, int zoom, struct fosphor_render *out);
 void  fosphor_amd_sink_set_frequency_range(fosphor_amd_sink *s, double center, double span);
 void  fosphor_amd_sink_set_fft_window(fosphor_amd_sink *s, const float *win);
 void  fosphor_amd_sink_set_visible(fosphor_amd_sink *s, int visible);
+/* Zero-copy feed (instead of work()): room for up to `want` contiguous samples in the pinned FIFO (*got of them; NULL and
+ * *got = 0 when the sink is not running or no room appears within timeout_ms); the producer writes them in place and
+ * commits n <= *got.  The region is DMA'd to the GPU from where it lies: no host copy at all. */
+void *fosphor_amd_sink_write_prepare(fosphor_amd_sink *s, int want, int *got, int timeout_ms);
+void  fosphor_amd_sink_write_commit(fosphor_amd_sink *s, int n);
 struct fosphor *fosphor_amd_sink_core(fosphor_amd_sink *s);
 void  fosphor_amd_sink_stats(fosphor_amd_sink *s, uint64_t *frames, uint64_t *samples, int *db_ref, int *db_per_div, int *frozen);
 

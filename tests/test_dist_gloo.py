@@ -149,6 +149,27 @@ try:
     raise SystemExit("rank %d: no error although rank 0 has no id" % rank)
 except RuntimeError as e:
     assert "rank 0" in str(e)
+# Two-phase set-up (the advisor's partial-failure case): build_native() is purely local, connect() is the collective part
+# (here: a real broadcast, which would block for ever if only one rank entered it).  When the local part fails on ONE
+# rank, NO rank enters connect(); when it works everywhere, every rank does.
+entered = []
+def local_native():
+    if rank == fail_on:
+        raise RuntimeError("no RCCL library can be bound in this process")
+    return Obj("native2")
+def connect(o):
+    entered.append(o.kind)
+    box = [bytes(range(128)) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)        # the id hand-off of NativeComm
+    assert box[0] == bytes(range(128))
+obj2, which2 = agree_on_transport(local_native, fallback, world, all_reduce_min, log=logs.append, connect=connect)
+assert which2 == want, (rank, which2)
+assert entered == (["native2"] if fail_on < 0 else []), (rank, entered)
+# ... and a collective part that fails on every rank alike (rank 0 has no id) also ends in the fallback everywhere
+def connect_fails(o):
+    NativeComm(FakeLib(True), rank, world)
+obj3, which3 = agree_on_transport(lambda: Obj("native3"), fallback, world, all_reduce_min, log=logs.append, connect=connect_fails)
+assert which3 == "fallback" and obj3.kind == "torch"
 # every rank ended on the same transport
 kinds = [None] * world
 dist.all_gather_object(kinds, obj.kind)

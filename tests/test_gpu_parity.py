@@ -11,6 +11,8 @@ Nothing here reads /root/reference.
 import errno
 import json
 import os
+import threading
+import time
 
 import numpy as np
 import pytest
@@ -565,6 +567,73 @@ def test_full_size_properties(amd, torch_cuda):
         q.close()
 
 
+def _bench_iq(torch, n_samples, seed, tone):
+    """the bench's synthetic input (white complex Gaussian, sigma 0.05 per component, generated on the device), optionally
+    with a tone so that the persistence state has structure; returns (device tensor, host copy)"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    d = torch.empty((n_samples, 2), dtype=torch.float32, device="cuda").normal_(0.0, 0.05, generator=g)
+    if tone:
+        t = torch.arange(n_samples, device="cuda", dtype=torch.float32)
+        d[:, 0] += 0.1 * torch.cos(0.61 * t)
+        d[:, 1] += 0.1 * torch.sin(0.61 * t)
+    torch.cuda.synchronize()
+    return d, d.cpu().numpy()
+
+
+def test_bench_launch_shape_vs_oracle(amd, torch_cuda, oracle_built):
+    """The launch shape bench.py times (BASELINE C2, the headline): 256 bins, ONE fosphor_amd_process_device call of
+    256 x 1024 spectra = 2^28 samples -- four 64-batch sub-launches on alternating FFT streams, relaxed input ordering --
+    then a second such call on the other half of the input ring, queued behind the first without a host wait in between.
+    Semantics: cl.c:870-968 applied 256 times per call.  The oracle takes the same 512 batches one fosphor_process at a
+    time: the last batch's hit counts equal it bit for bit and the state every one of the 512 batches went into --
+    persistence histogram, live, max-hold, waterfall ring, ring position -- is in tolerance."""
+    torch = torch_cuda
+    F, B = 256, 1024
+    threads = min(os.cpu_count() or 1, 64)
+    f = amd.Fosphor(n_bins=256, max_spectra=F * B, max_batches=F, stream=torch.cuda.current_stream().cuda_stream)
+    f.set_input_ordering(False)				# bench.py's default: the ring is written once, before the first call
+    o = Oracle(n_bins=256)
+    halves = [_bench_iq(torch, F * B * 1024, 7 + h, tone=bool(h)) for h in range(2)]
+    for d, _ in halves:					# both calls in flight together, as in the timed loop
+        assert f.process_device(d, F, B) == 0
+    assert f.finish() >= 0
+    for _, x in halves:
+        for k in range(F):
+            assert o.process(x[k * B * 1024:(k + 1) * B * 1024], nthreads=threads) == 0
+    compare_state(f, o, "bench launch shape, batch mode (2 calls x 256 batches)")
+    f.close()
+
+
+def test_bench_frame_mode_shape_vs_oracle(amd, torch_cuda, oracle_built):
+    """`bench.py --mode frame` (what every rank of the multi-GPU bench runs; here one rank, no exchange): the 256 x 1024
+    spectra of a step are ONE display frame -- accumulate_device (sub-launched K1s, count kernels taking several chunks,
+    k2c_sum) then one merge with fft_batch = 262144, i.e. one reference display launch over the whole frame (the kernel is
+    batch-generic, only the host caps it: cl.c:885).  Two frames back to back, against the oracle's two such launches."""
+    torch = torch_cuda
+    from gr_fosphor_amd.dist import ShardedFosphor
+    F, B = 256, 1024
+    threads = min(os.cpu_count() or 1, 64)
+    sf = ShardedFosphor(amd.Fosphor, 0, 1, n_bins=256, max_spectra=F * B, max_batches=F)
+    sf.f.set_input_ordering(False)
+    o = Oracle(n_bins=256)
+    frames = [_bench_iq(torch, F * B * 1024, 17 + h, tone=bool(h)) for h in range(2)]
+    for d, _ in frames:
+        sf.frame(d, F * B, overlap=True, wait_producer=False)
+    sf.flush()
+    assert sf.f.finish() >= 0
+    for _, x in frames:
+        assert o.process(x, strict=False, nthreads=threads) == 0
+    f = sf.f
+    assert f.waterfall_pos == o.waterfall_pos
+    assert np.array_equal(f.hitcount, o.hitcount.T), "frame mode: hit counts differ"
+    assert_close(f.waterfall, o.waterfall, "frame mode waterfall")
+    assert_close(f.spectrum[0, :, 1], o.spectrum[0, :, 1], "frame mode live")
+    assert_close(f.spectrum[1, :, 1], o.spectrum[1, :, 1], "frame mode max-hold")
+    assert_hist_close(f.histogram, o.histogram, "frame mode histogram")
+    sf.close()
+
+
 def test_sharded_batch_equals_single_launch(amd, torch_cuda, oracle_built):
     """The multi-GPU split run on one device: two 'ranks' each accumulate half of one 2048-spectrum
     batch, the partial arrays are combined the way the all-reduce would (sum, sum, max), one merge:
@@ -964,6 +1033,90 @@ def test_sink_zoom_pane_and_click_to_frequency(amd, torch_cuda):
     assert L.fosphor_amd_sink_mouse_action(s, 0, xz, yz, C.byref(freq)) == 1
     assert freq.value == L.fosphor_pos2freq(core, C.byref(z), xz)
     assert abs(freq.value - 433.92e6) < 0.2 * 2.0e6					# the zoom pane spans 20 % around the centre
+
+    # the "freq" callback runs with no lock of the sink held (the reference publishes its message unlocked,
+    # base_sink_c_impl.cc:385,390): a callback that re-enters the sink must not deadlock
+    seen = []
+    CB = C.CFUNCTYPE(None, C.c_double, C.c_void_p)
+
+    def on_freq(fv, _user):
+        rr = amd.Render()
+        L.fosphor_amd_sink_get_render(s, 1, C.byref(rr))			# takes the render lock
+        inner = C.c_double()
+        depth = len(seen)
+        seen.append(fv)
+        if depth == 0:								# one level of re-entry through the click path itself
+            assert L.fosphor_amd_sink_mouse_action(s, 0, xz, yz, C.byref(inner)) == 1
+            assert inner.value == fv
+
+    cb = CB(on_freq)
+    L.fosphor_amd_sink_set_freq_callback(s, C.cast(cb, C.c_void_p), None)
+    done = []
+    th = threading.Thread(target=lambda: done.append(L.fosphor_amd_sink_mouse_action(s, 0, xz, yz, C.byref(freq))))
+    th.start()
+    th.join(20.0)
+    assert not th.is_alive(), "execute_mouse_action deadlocked on a re-entrant callback"
+    assert done == [1] and len(seen) == 2 and seen[0] == seen[1] == freq.value
+    L.fosphor_amd_sink_set_freq_callback(s, None, None)
+    L.fosphor_amd_sink_stop(s)
+    L.fosphor_amd_sink_free(s)
+
+
+# PCIe-inclusive floor for the streaming sink fed through work() (GSamples/s; 8 B per sample over a Gen5 x16 link:
+# 7.9 GSamples/s is the bound).  FOSPHOR_SINK_FLOOR overrides it on a loaded or slower host.
+SINK_WORK_FLOOR = float(os.environ.get("FOSPHOR_SINK_FLOOR", "3.0"))
+
+
+def test_sink_zero_copy_feed(amd, torch_cuda, oracle_built):
+    """The zero-copy producer interface: the source writes its samples straight into the pinned FIFO
+    (write_prepare / write_commit) and the host copy of work() disappears.  Same results as work(); and the rate of
+    the sink alone -- regions committed as they are -- is reported (PCIe-bound)."""
+    import ctypes as C
+    L = amd.load()
+    n_spec = 2048 + 512
+    x = add_tone(gaussian_iq(n_spec * 1024, 53), 0.1, 0.21)
+    flat = np.ascontiguousarray(x).reshape(-1)
+    s = L.fosphor_amd_sink_new_len(1 << 22)
+    got = C.c_int()
+    assert L.fosphor_amd_sink_write_prepare(s, 1 << 16, C.byref(got), 10) is None and got.value == 0	# not running
+    assert L.fosphor_amd_sink_start(s) == 1
+    pos, total = 0, n_spec * 1024
+    while pos < total:
+        p = L.fosphor_amd_sink_write_prepare(s, min(1 << 19, total - pos), C.byref(got), 1000)
+        assert p and got.value > 0
+        dst = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(got.value * 2,))
+        dst[:] = flat[2 * pos:2 * (pos + got.value)]				# "the driver's receive call"
+        L.fosphor_amd_sink_write_commit(s, got.value)
+        pos += got.value
+    samples = C.c_uint64()
+    for _ in range(2000):
+        L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+        if samples.value == total:
+            break
+        time.sleep(0.005)
+    assert samples.value == total
+    core = L.fosphor_amd_sink_core(s)
+    wf = np.empty((1024, 1024), np.float32)
+    assert L.fosphor_amd_read(core, 0, wf.ctypes.data, wf.nbytes) == 0
+    o = Oracle()
+    for k in range(0, n_spec, 512):
+        o.process(x[k * 1024:(k + 512) * 1024], nthreads=8)
+    assert_close(wf, o.waterfall, "sink waterfall after a zero-copy feed")
+    # rate of the sink alone: commit regions as they lie (whatever the ring holds), 1 Mi samples at a time
+    t0 = time.perf_counter()
+    n_rate = 0
+    while n_rate < (1 << 30):
+        p = L.fosphor_amd_sink_write_prepare(s, 1 << 20, C.byref(got), 1000)
+        assert p
+        L.fosphor_amd_sink_write_commit(s, got.value)
+        n_rate += got.value
+    want = total + (n_rate & ~(16 * 1024 - 1))
+    while samples.value < want:
+        L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
+        assert time.perf_counter() - t0 < 60.0
+    rate = n_rate / (time.perf_counter() - t0) / 1e9
+    print("sink, zero-copy feed: %.2f GSamples/s (no host copy; PCIe Gen5 x16 bound 7.9)" % rate)
+    assert rate > SINK_WORK_FLOOR
     L.fosphor_amd_sink_stop(s)
     L.fosphor_amd_sink_free(s)
 
@@ -999,7 +1152,7 @@ def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built)
     assert dt > 0
     rate = reps * n_spec * 1024 / dt / 1e9
     print("sink, native feed: %.2f GSamples/s through work()" % rate)
-    assert rate > 0.75, "streaming sink moved only %.2f GSamples/s" % rate
+    assert rate > SINK_WORK_FLOOR, "streaming sink moved only %.2f GSamples/s" % rate
     L.fosphor_amd_sink_stop(s)
     # a sink that is not running takes nothing and says so instead of blocking for ever (work() returns 0, the feed gives up)
     assert L.fosphor_amd_sink_work(s, flat.ctypes.data, 1 << 16) == 0
@@ -1031,16 +1184,24 @@ def test_fft8192_bit_exact(amd, torch_cuda, oracle_built):
     f.close()
 
 
-def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built):
-    """8192-point FFT, 512 bins, overlap 2 fused into the read, two launches with state carry-over."""
+@pytest.mark.parametrize("overlap,tile,k1w", [(2, None, "1"), (2, "32", "1"), (2, "64", "1"), (4, "32", "1"), (8, "64", "1"),
+                                              (16, "32", "1"), (2, "64", "0"), (4, None, "0")])
+def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overlap, tile, k1w):
+    """8192-point FFT, 512 bins, overlap_cc fused into the read, two launches with state carry-over.  The overlapped part of a
+    window is reused from registers through one branch per ratio (overlap 2 / 4 / 8; 16 reloads everything), at the tile
+    lengths the real C3 launch uses (32, 64) as well as the short ones small launches pick, and through the general kernel
+    (FOSPHOR_AMD_K1W=0, what odd hops fall back to)."""
     torch = torch_cuda
-    n, nb, overlap = 8192, 512, 2
+    n, nb = 8192, 512
     hop = n // overlap
+    if tile:
+        monkeypatch.setenv("FOSPHOR_AMD_TILE", tile)
+    monkeypatch.setenv("FOSPHOR_AMD_K1W", k1w)
     f = amd.Fosphor(fft_len_log=13, n_bins=nb, max_spectra=128)
     o = Oracle(fft_len_log=13, n_bins=nb)
     assert f.histo_scale == o.histo_scale and f.histo_offset == o.histo_offset
     t0 = 0
-    for call, n_spec in enumerate([32, 64]):
+    for call, n_spec in enumerate([64, 128] if tile == "64" else [32, 64]):
         x = add_tone(gaussian_iq((n_spec - 1) * hop + n, 81 + call), 0.05, 0.0313, t0=t0)
         t0 += x.shape[0]
         expanded = np.concatenate([x[i * hop:i * hop + n] for i in range(n_spec)])
