@@ -351,14 +351,12 @@ def main():
                     break
             if traffic:
                 break
-        fused16 = os.environ.get("FOSPHOR_AMD_K1H_FUSED", "1")[:1] != "0"
         # (the launch condition of launch_k1: k1w_fft_bin unless FOSPHOR_AMD_K1W=0 or the hop is odd)
         k1w = os.environ.get("FOSPHOR_AMD_K1W", "1")[:1] != "0" and not (hop & 1)
         k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)",
                    13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, overlap reused from registers)" if k1w else
                        "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
-                   16: "k1h_fused (K1, both LDS stages in one kernel, intermediate in the XCD's L2)" if fused16 else
-                       "k1h_stage_a + k1h_stage_b (K1, two LDS stages, two kernels)"}[cfg["log2n"]]
+                   16: "k1h_fused (K1, radix-16 plan: two 256-point levels in one kernel, intermediate in the XCD's L2)"}[cfg["log2n"]]
         if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
             k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"
         sub_b = samples_per_launch / samples_per_batch

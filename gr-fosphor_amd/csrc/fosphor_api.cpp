@@ -133,7 +133,7 @@ struct fosphor
 	float     rise_t0r, rise_t0d;
 	int       slot;				/* partial-array slot used by accumulate/merge */
 	float2   *d_scratch;			/* N = 65536: [max_spectra][N] spectrum between the two FFT stages */
-	int       k1h_fused;			/* N = 65536: both stages in one kernel, the intermediate in the XCDs' L2 (FOSPHOR_AMD_K1H_FUSED=0: two kernels) */
+	int       k1h_fused;			/* N = 65536: both levels of the plan in one kernel, the intermediate in the XCDs' L2 (always 1 since round 4) */
 	uint32_t *d_k1h_sync;			/* its cluster counters */
 	uint32_t *h_k1h_err;			/* ... and its error word (host memory the kernel writes: work-groups of a cluster on different XCDs) */
 
@@ -173,11 +173,42 @@ struct fosphor
  * native_sin/native_cos pinned to fosphor_portable_math.h.  Layout: one block per radix-8 pass
  * with p = 8, 64, 512, ... < N/2 ([k < p][n = 1..7]), then the final radix-2 pass ([k < N/2]).
  * For N = 1024 this is the kTw2Off / kTw3Off / kTw4Off layout of fosphor_internal.h. */
+/* N = 65536 runs this build's own radix-16 plan (oracle/fosphor_oracle.c o_dft16 / o_pass_radix16): the four constant
+ * rotations W16^1,3,5,7 of dft16, then one block per twiddled pass p = 16, 256, 4096 ([k < p][j = 1..15], angle
+ * -pi k / (8 p) -- the reference's expression with 16 in the place of 8). */
+static int build_twiddles16(float2 *tw, int *offsets /* [8] or NULL */)
+{
+	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
+	int pos = 0, q = 0;
+	if (offsets) offsets[q] = pos;
+	q++;
+	for (int j = 1; j < 8; j += 2) {
+		const float a16 = -PI_F / 8.0f;
+		const float arg = (float)j * a16;
+		if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+		pos++;
+	}
+	for (int p = 16; p <= 4096; p *= 16, q++) {
+		if (offsets) offsets[q] = pos;
+		for (int k = 0; k < p; k++) {
+			const float alpha = -PI_F * (float)k / (float)(8 * p);
+			for (int f = 1; f < 16; f++) {
+				const float arg = (float)f * alpha;
+				if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+				pos++;
+			}
+		}
+	}
+	return pos;
+}
+
 static int build_twiddles(float2 *tw, int log2n, int *offsets /* [8] or NULL */)
 {
 	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
 	const int n = 1 << log2n;
 	int pos = 0, q = 0;
+	if (log2n == 16)
+		return build_twiddles16(tw, offsets);
 	for (int p = 8; p < n / 2; p *= 8, q++) {
 		if (offsets) offsets[q] = pos;
 		for (int k = 0; k < p; k++) {
@@ -426,14 +457,11 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->d_bins = self->d_bins_pp[0];
 	self->d_partial = self->d_partial_pp[0];
 	if (self->log2n == 16) {
-		/* Default: alone the fused kernel beats the two-kernel form (346 us per 1024-spectrum frame against 376 with two
-		 * frames overlapping, 461 without) and moves 1.7 x less through the fabric; it cannot share a CU with the count
-		 * kernel, so the whole path is level with the two-kernel form (133-137 against 134-135 GSamples/s),
-		 * DESIGN.md section 8.  FOSPHOR_AMD_K1H_FUSED=0: two kernels. */
-		const char *e = getenv("FOSPHOR_AMD_K1H_FUSED");
-		self->k1h_fused = !(e && *e == '0');
-		/* two kernels: the whole launch's intermediate; fused: 512 KiB per cluster (kept at 64 clusters' worth) */
-		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)(self->max_spectra < 64 ? 64 : self->max_spectra) * self->n), "alloc stage scratch");
+		/* One FFT kernel takes a spectrum through both 256-point levels of the radix-16 plan, the intermediate staying in the
+		 * XCD's L2 (the two-kernel form of rounds 1-3 went with the radix-8 plan in round 4). */
+		self->k1h_fused = 1;
+		/* 512 KiB of intermediate per cluster, at most 8 clusters on each of the 8 XCDs */
+		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)64 * self->n), "alloc cluster intermediates");
 		HIP_TRY(hipMalloc((void **)&self->d_k1h_sync, sizeof(uint32_t) * 64 * 64), "alloc cluster counters");
 		HIP_TRY(hipMemset(self->d_k1h_sync, 0, sizeof(uint32_t) * 64 * 64), "clear cluster counters");
 		HIP_TRY(hipHostMalloc((void **)&self->h_k1h_err, 64, hipHostMallocMapped), "alloc error word");
@@ -687,11 +715,12 @@ static int pick_tile(const struct fosphor *self, int total, int batch)
 {
 	const char *e = getenv("FOSPHOR_AMD_TILE");
 	const int v = e ? atoi(e) : 0;
-	if (v >= 4 && v <= 128 && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
+	if (v >= 4 && v <= (self->log2n == 16 ? 32 : 128) && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
 		return v;
 	if (self->log2n == 16 && self->k1h_fused) {
-		/* a cluster owns whole tiles: the largest tile that still gives each of the 32 clusters one */
-		for (int t = 64; t >= 8; t >>= 1)
+		/* a cluster owns whole tiles: the largest tile that still gives each of the 32 clusters one (at most 32 spectra: the
+		 * 9th bits of a tile's bin indices share one dword per column) */
+		for (int t = 32; t >= 8; t >>= 1)
 			if (batch % t == 0 && total / t >= 32)
 				return t;
 		return 4;
@@ -821,6 +850,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 		k2.hc16 = self->d_slab16, k2.rowmask = NULL;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
 	k2.n = self->n; k2.bins16 = self->bins16;
+	k2.bins9 = (self->log2n == 16); k2.total = n_batches * batch;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
@@ -1232,7 +1262,7 @@ extern "C" int fosphor_amd_finish(struct fosphor *self)
 		return -EIO;
 	if (self->h_k1h_err && self->h_k1h_err[0]) {
 		fprintf(stderr, "[fosphor_amd] fused 65536-point FFT: a cluster wait timed out (code 0x%x); "
-		        "results are invalid (set FOSPHOR_AMD_K1H_FUSED=0)\n", self->h_k1h_err[0]);
+		        "results are invalid\n", self->h_k1h_err[0]);
 		self->h_k1h_err[0] = 0;
 		return -EIO;
 	}
@@ -1452,6 +1482,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				k2.hc = self->d_hc + (size_t)self->slot * cells;
 				k2.hc16 = self->d_slab16 + (size_t)(c0 / G) * cells;
 				k2.n = self->n; k2.bins16 = self->bins16;
+				k2.bins9 = (self->log2n == 16); k2.total = sub_total;
 				k2.batch = sub_total; k2.chunk = 1024 * G; k2.tile = tile; k2.n_bins = self->n_bins;
 				k2.w = 1.0f - self->alpha;
 				k2.log2_w = (float)log2((double)(1.0f - self->alpha));

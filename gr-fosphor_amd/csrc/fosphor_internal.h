@@ -32,7 +32,8 @@ struct K1Params {
 	int   hop;			/* samples between spectrum starts: N, or N/overlap (overlap_cc_impl.cc:74-76) */
 	int   n, log2n;			/* FFT length */
 	int   bins16;			/* 16-bit bin indices, 2 spectra per dword (general kernel) */
-	int   tw_off[8];		/* twiddle block offsets: radix-8 passes p = 8, 64, ...; then the radix-2 pass */
+	int   tw_off[8];		/* twiddle block offsets: radix-8 passes p = 8, 64, ...; then the radix-2 pass
+					 * (N = 65536, radix-16 plan: W16 constants, then p = 16, 256, 4096) */
 	const float  *win;		/* [N] */
 	const float2 *tw;		/* [kTwLen] */
 	const double *thr;		/* [n_bins + 1] exact squared-magnitude thresholds */
@@ -41,9 +42,9 @@ struct K1Params {
 	float        *wf;		/* [wf_rows][N] */
 	float2       *fft_out;		/* test hook, or nullptr */
 	long long    *dbg;		/* K1_TIMING builds: [waves][8] cycle accumulators, or nullptr */
-	float2       *scratch;		/* variant 4: [total][N] intermediate spectrum between the two stages */
+	float2       *scratch;		/* variant 4: [64 clusters][N] intermediate spectrum between the two stages */
 	int   iq_half;			/* variant 4: the IQ stream is fp16 (re, im) pairs, 4 B per sample */
-	uint32_t *sync;			/* variant 4, fused form: cluster counters [64][64]; nullptr = two kernels */
+	uint32_t *sync;			/* variant 4: cluster counters [64][64] */
 	uint32_t *sync_err;		/* ... its error word (host-mapped): set when a bounded cluster wait times out */
 	int   dbg_k1h;			/* measurement only (FOSPHOR_AMD_DBG_K1H): 1 no cluster waits, 2 no IQ loads, 4 no row / bin stores,
 					 * 8 no intermediate stores / loads -- results are wrong with any of them */
@@ -76,6 +77,9 @@ struct K2Params {
 	float    *chunk_max;		/* [n_chunks][N] */
 	int   n;			/* FFT length (columns) */
 	int   bins16;			/* bin indices are 16-bit, 2 spectra per dword */
+	int   bins9;			/* N = 65536: low bytes as [total / 4][N] dwords (4 spectra per dword), then the 9th bits as
+					 * [total / tile][N] dwords (bit u = spectrum u of the tile) */
+	int   total;			/* spectra of the FFT launch that wrote `bins` (locates the 9th-bit plane) */
 	int   batch;			/* spectra per batch in this launch */
 	int   chunk;			/* spectra per chunk; divides batch */
 	int   tile;

@@ -1242,289 +1242,120 @@ void k1w_fft_bin(const K1Params p)
 }
 
 /* ------------------------------------------------------------------------ */
-/* K1 for N = 65536: two LDS stages                                           */
+/* K1 for N = 65536: radix-16 plan, two stages, the intermediate in the XCD's L2 */
 /* ------------------------------------------------------------------------ */
-/* The plan for N = 8^5 * 2 is five radix-8 Stockham passes (p = 1, 8, 64, 512, 4096) and the
- * radix-2 pass (p = 32768), 8192 virtual work-items of 8 points (the generalisation of
- * fft.cl:397-466 the oracle defines).  512 KiB per spectrum does not fit one CU's LDS, but the
- * data flow of the plan factors:
+/* No reference behaviour exists at N = 65536 (fft.cl has one length, 1024): the plan is this build's own and the oracle
+ * restates it (oracle/fosphor_oracle.c, o_dft16 / o_pass_radix16): four Stockham radix-16 passes, p = 1, 16, 256, 4096,
+ * 4096 virtual work-items of 16 points, with dft16 = one radix-2 stage + the reference's dft8 twice.  512 KiB per
+ * spectrum does not fit one CU's LDS, but the data flow factors into two 256-point levels:
  *
- *   stage A  passes 1-3 only mix inputs whose index is congruent mod 128: for each residue q they
- *            ARE the three passes of a 512-point Stockham FFT (twiddles depend on p and k = i & (p-1)
- *            only) on x[q + 128 m], m < 512, and leave their 512 results CONTIGUOUS at [512 q, 512 q + 512).
- *            One work-group takes 16 adjacent residues (64-byte runs of fp16 IQ / 128-byte runs of fp32).
- *   stage B  passes 4, 5 and the radix-2 pass only mix elements with the same offset k inside those
- *            blocks: for each k < 512 a 128-point (8 x 8 x 2) transform over w[512 q + k], q < 128, whose
- *            twiddle indices are k (p = 512), k + 512 jj4 (p = 4096) and k + 512 jj4 + 4096 jj5 (radix 2),
- *            and whose outputs are columns k + 512 m, m < 128.  One work-group takes 32 adjacent k
- *            (256-byte runs), and carries the same epilogue as the other K1 kernels.
+ *   stage A  passes 1-2 only mix inputs whose index is congruent mod 256: for each residue q they ARE the two passes of a
+ *            256-point transform on x[q + 256 m], m < 256, and leave its 256 results at w[256 q + kk], kk < 256.
+ *            SIXTEEN LANES do one such transform (16 points each, one 16 x 16 transpose through LDS in between), so a
+ *            wavefront does four residues ON ITS OWN: no work-group barrier anywhere in stage A.
+ *   stage B  passes 3-4 only mix elements with the same offset kk: for each kk a 256-point transform over w[256 q + kk],
+ *            q < 256, whose outputs are columns kk + 256 jj3 + 4096 jj4.  A work-group takes 32 adjacent offsets with
+ *            thread = (offset, item): every global access of the stage -- the intermediate coming in, rows, bin indices
+ *            and partials going out -- is a run of 32 consecutive columns (128 / 256 B), and the one exchange between its
+ *            two passes goes through a work-group-wide LDS array behind ONE barrier.
  *
- * Between the stages the spectrum makes one round trip through HBM / the Infinity Cache as fp32
- * (8 B per sample written and read).  Arithmetic: the same c_mul / dft8 / DFT2 as every other variant,
- * hence the same bits as the oracle.  fp16 IQ is widened on load (exact). */
-template <bool HALF>
-__global__ __launch_bounds__(1024, 8)		/* <= 64 VGPRs: two 16-wave work-groups per CU (68 left room for one) */
-void k1h_stage_a(const K1Params p)
+ * A CLUSTER of 8 work-groups on ONE XCD takes a spectrum through both stages (member m: residues [32 m, 32 m + 32) in stage A,
+ * offsets [32 m, 32 m + 32) in stage B); between the stages the spectrum makes one round trip through the XCD's L2 (plain
+ * stores + s_waitcnt vmcnt(0) + relaxed agent-scope atomics: the L2 is the coherence point of its CUs), laid out
+ * [offset / 32][residue][offset % 32] so that both sides move whole 128-byte runs.  Clusters form from XCC_ID tickets and
+ * claim tiles dynamically (progress never depends on a work-group that is not resident); every wait on another work-group
+ * is bounded and ends in an error word the host turns into -EIO.
+ *
+ * Against the radix-8 form this replaces (8.8.8 | 8.8.2, 1024 threads of 8 points, eight work-group barriers per spectrum):
+ * 512 threads of 16 points, ONE work-group barrier per spectrum besides the cluster hand-off, twiddles of a thread fixed
+ * for its lifetime (registers / two small LDS tables), ~40 % fewer instructions per sample.
+ *
+ * Bin indices: 512 bins need 9 bits.  The low 8 bits go out like the 1024-point path's (one dword = 4 consecutive spectra of
+ * a column), the 9th as one bit per spectrum in a dword per (tile, column): 1.125 B per sample instead of 2. */
+
+/* X[jj] of dft16 sits in r[bitrev4(jj)] */
+#define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))
+
+/* o_dft16: radix-2 stage, W16^j on the odd half (full products for odd j, the reference's constant rotations for j = 2, 4,
+ * 6 -- the one by -j folded into the butterfly that consumes it), then dft8 on each half */
+static __device__ __forceinline__ void dft16(v2f (&r)[16], v2f s12, const v2f (&c16)[4])
 {
-	constexpr int N = 65536, QA = 16, M = 512, TS = 64, ROW = M + 1;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	v2f *buf = reinterpret_cast<v2f *>(smem_raw) + (threadIdx.x & (QA - 1)) * ROW;	/* this residue's row */
-	const int ql = threadIdx.x & (QA - 1);
-	const int i  = threadIdx.x >> 4;				/* sub-FFT work-item, 0..63 */
-	/* twiddles of passes 2 and 3 (p = 8, 64: the first 504 table entries) behind the rows, in LDS */
-	v2f *tws = reinterpret_cast<v2f *>(smem_raw) + QA * ROW;
-	for (int k = threadIdx.x; k < (8 + 64) * 7; k += 1024)
-		tws[k] = reinterpret_cast<const v2f *>(p.tw)[k];
-	__syncthreads();
-	const v2f *twg = tws;
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
-	const int nwork = p.total * (128 / QA);
-
-	for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-		const int t = work >> 3, q0 = (work & 7) * QA, q = q0 + ql;
-		v2f r[8];
-
-		/* load x[q + 128 (i + 64 j)] and window (fft.cl:415-417) */
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int n = q + 128 * (i + TS * j);
-			v2f xv;
-			if (HALF) {
-				typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-				const h2 h = reinterpret_cast<const h2 *>(p.iq)[(size_t)t * p.hop + n];
-				xv = v2f{ (float)h.x, (float)h.y };			/* v_cvt_f32_f16: exact */
-			} else {
-				xv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p.iq + (size_t)t * p.hop + n));
-			}
-			const float wv = p.win[n];
-			r[j] = v2f{ xv.x * wv, xv.y * wv };
-		}
-
-		/* passes p = 1, 8, 64 of the 512-point sub-plan (fft.cl:278-350 with t = 64) */
-		int pp = 1;
+	for (int j = 0; j < 8; j++)
+		DFT2(r[j], r[j + 8]);
+	r[9]  = c_mul(r[9], c16[0]);
+	r[10] = mul_p1q4(r[10], s12);
+	r[11] = c_mul(r[11], c16[1]);
+	/* r[12] = mul_p1q2(r[12]): folded into the first butterfly of the second dft8 */
+	r[13] = c_mul(r[13], c16[2]);
+	r[14] = mul_p3q4(r[14], s12);
+	r[15] = c_mul(r[15], c16[3]);
+	{
+		v2f a[8];
 #pragma unroll
-		for (int q8 = 0; q8 < 3; q8++) {
-			const int k = i & (pp - 1);
-			if (q8 > 0) {
-				const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
+		for (int j = 0; j < 8; j++) a[j] = r[j];
+		dft8(a, s12);
 #pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(r[j], tw[j - 1]);
-			}
-			dft8(r, s12);
-			const int j0 = ((i - k) << 3) + k;
+		for (int j = 0; j < 8; j++) r[j] = a[j];
+	}
+	{
+		v2f b[8];
 #pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				buf[j0 + jj * pp] = r[R8_PERM(jj)];
-			__syncthreads();
-			if (q8 < 2) {
+		for (int j = 0; j < 8; j++) b[j] = r[8 + j];
+		/* dft8 (fft.cl:112-145) with b[4] still to be rotated by -j */
+		DFT2_MJ(b[0], b[4]); DFT2(b[1], b[5]); DFT2(b[2], b[6]); DFT2(b[3], b[7]);
+		b[5] = mul_p1q4(b[5], s12); b[7] = mul_p3q4(b[7], s12);
+		DFT2(b[0], b[2]); DFT2(b[1], b[3]); DFT2_MJ(b[4], b[6]); DFT2(b[5], b[7]);
+		DFT2(b[0], b[1]); DFT2_MJ(b[2], b[3]); DFT2(b[4], b[5]); DFT2_MJ(b[6], b[7]);
 #pragma unroll
-				for (int j = 0; j < 8; j++)
-					r[j] = buf[i + TS * j];
-				__syncthreads();
-			}
-			pp <<= 3;
-		}
-
-		/* the 16 blocks of 512 results, contiguous in the intermediate spectrum */
-		{
-			const v2f *all = reinterpret_cast<const v2f *>(smem_raw);
-			v2f *dst = reinterpret_cast<v2f *>(p.scratch) + (size_t)t * N + (size_t)M * q0;
-			for (int idx = threadIdx.x; idx < QA * M; idx += 1024)
-				dst[idx] = all[(idx >> 9) * ROW + (idx & (M - 1))];
-		}
-		__syncthreads();
+		for (int j = 0; j < 8; j++) r[8 + j] = b[j];
 	}
 }
 
-template <bool WRITE_FFT>
-__global__ __launch_bounds__(512)
-void k1h_stage_b(const K1Params p)
+/* Buffer addressing for the 65536-point kernel: every global access of its loop is `scalar base (descriptor) + ONE 32-bit per-lane
+ * offset + a scalar offset` -- buffer_load / buffer_store ... offen -- where the per-lane offset is fixed for the kernel's lifetime and
+ * everything that changes (spectrum, row, column block c) is scalar arithmetic.  With plain pointers the compiler folded the
+ * column-block constants into 64-bit per-lane adds (240 of them per spectrum) and spilled.  Arrays addressed this way are < 4 GiB. */
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
 {
-	constexpr int N = 65536, KB = 32;
-	__shared__ v2f l4[128 * KB];			/* after pass 4: [(i3, jj4)][k] */
-	__shared__ v2f l5[128 * KB];			/* after pass 5: [(i4, jj5, jj4)][k] */
-	const int kl = threadIdx.x & (KB - 1);
-	const int a  = threadIdx.x >> 5;			/* 0..15 */
-	const int kgroups = 512 / KB;				/* 16 */
-	const int ntiles = p.total / p.tile;
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
-	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
-	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
-	const float top = (float)(bk.nb - 1);
-
-	for (int work = blockIdx.x; work < ntiles * kgroups; work += gridDim.x) {
-	const int tile = work / kgroups, k = (work - tile * kgroups) * KB + kl;
-	const int t0 = tile * p.tile;
-	float live[8], vmax[8];
-#pragma unroll
-	for (int q = 0; q < 8; q++) { live[q] = 0.0f; vmax[q] = vmax_init; }
-
-	for (int g0 = 0; g0 < p.tile; g0 += 2) {
-		uint32_t pack[8];
-#pragma unroll
-		for (int q = 0; q < 8; q++) pack[q] = 0;
-
-#pragma unroll 1
-		for (int u = 0; u < 2; u++) {
-			const int t = t0 + g0 + u;
-			const v2f *w = reinterpret_cast<const v2f *>(p.scratch) + (size_t)t * N;
-			v2f r[8];
-
-			/* pass 4, p = 512: item i3 = a combines blocks q = a + 16 j at offset k; twiddle index k */
-#pragma unroll
-			for (int j = 0; j < 8; j++)
-				r[j] = w[512 * (a + 16 * j) + k];
-			{
-				const v2f *tw = twg + p.tw_off[2] + k * 7;
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(r[j], tw[j - 1]);
-			}
-			dft8(r, s12);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				l4[(a * 8 + jj) * KB + kl] = r[R8_PERM(jj)];
-			__syncthreads();
-
-			/* pass 5, p = 4096: item (i4, jj4) combines i3 = i4 + 2 j; twiddle index k + 512 jj4 */
-			{
-				const int i4 = a >> 3, jj4 = a & 7;
-#pragma unroll
-				for (int j = 0; j < 8; j++)
-					r[j] = l4[((i4 + 2 * j) * 8 + jj4) * KB + kl];
-				const v2f *tw = twg + p.tw_off[3] + (k + 512 * jj4) * 7;
-#pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(r[j], tw[j - 1]);
-				dft8(r, s12);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					l5[(i4 * 64 + jj * 8 + jj4) * KB + kl] = r[R8_PERM(jj)];
-			}
-			__syncthreads();
-
-			/* radix-2 pass, p = 32768 (fft.cl:428-458): butterflies on columns (j, j + 32768),
-			 * j = k + 512 m, m = 4a + c; twiddle index j */
-			v2f x[8];
-#pragma unroll
-			for (int c = 0; c < 4; c++) {
-				const int m = 4 * a + c;
-				const int jcol = k + 512 * m;
-				v2f va = l5[m * KB + kl];
-				v2f vb = l5[(64 + m) * KB + kl];
-				vb = c_mul(vb, twg[p.tw_off[4] + jcol]);
-				DFT2(va, vb);
-				x[c] = va;
-				x[c + 4] = vb;
-			}
-			/* (l4 is rewritten only after the next spectrum's first barrier; l5 after its second) */
-
-			if (WRITE_FFT) {
-#pragma unroll
-				for (int c = 0; c < 4; c++) {
-					const int jcol = k + 512 * (4 * a + c);
-					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol] = x[c];
-					reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol + N / 2] = x[c + 4];
-				}
-			}
-
-			/* epilogue (display.cl:136,161-168), 16-bit bin indices */
-			float l2[8];
-			uint32_t bn[8];
-			uint32_t amb = 0;
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				uint32_t ab;
-				const float rr = bin_fast(x[q].x, x[q].y, bk, &l2[q], &ab);
-				amb = amb > ab ? amb : ab;
-				bn[q] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
-			}
-			if (amb > __float_as_uint(bk.amb)) {
-#pragma unroll
-				for (int q = 0; q < 8; q++) {
-					const float v = __builtin_fmaf(bk.A, l2[q], bk.C);
-					const float rr = __builtin_rintf(v);
-					const float am = __builtin_fmaf(__builtin_fabsf(l2[q]), bk.kappa, __builtin_fabsf(v - rr));
-					if (!(am <= bk.amb)) {
-						float nl2;
-						bn[q] = bin_exact(x[q].x, x[q].y, l2[q], (int)bn[q], bk.thr, bk.nb, &nl2);
-						l2[q] = nl2;
-					}
-				}
-			}
-			const bool store_row = (t >= p.wf_first);
-			float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * N;
-#pragma unroll
-			for (int q = 0; q < 8; q++) {
-				const int col = k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2);
-				pack[q] |= bn[q] << (16 * u);
-				live[q] = __builtin_fmaf(live[q], p.w, l2[q]);
-				vmax[q] = max_f32(vmax[q], l2[q]);
-				if (store_row)
-					wf_row[col] = l2[q] * F_HALF_LOG10_2;
-			}
-		}
-		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 1) * N;
-#pragma unroll
-		for (int q = 0; q < 8; q++)
-			dst[k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2)] = pack[q];
-	}
-	float2 *pp2 = p.partial + (size_t)tile * N;
-#pragma unroll
-	for (int q = 0; q < 8; q++)
-		pp2[k + 512 * (4 * a + (q & 3)) + (N / 2) * (q >> 2)] = make_float2(live[q] * F_HALF_LOG10_2,
-			(vmax[q] == vmax_init) ? -1000.0f : vmax[q] * F_HALF_LOG10_2);
-	__syncthreads();		/* all reads of l5 done before the next work item's first stores */
-	}
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);	/* raw buffer, 32-bit data format */
+}
+constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of the buffer intrinsics: nt, sc1 */
+template <int AUX>
+static __device__ __forceinline__ void bst_v2f(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+	__builtin_amdgcn_raw_buffer_store_b64(u2v{ __float_as_uint(v.x), __float_as_uint(v.y) }, rs, voff, soff, AUX);
+}
+template <int AUX>
+static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+	const u2v u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
+	return v2f{ __uint_as_float(u.x), __uint_as_float(u.y) };
 }
 
-/* ---- both stages in one kernel, the intermediate spectrum resident in the XCD's L2 ---------------------------
- * The two-kernel form above moves 8 B per sample out of the L2 and 8 B back in (next to 4 B of fp16 IQ): the
- * L2 <-> fabric links, not the Infinity Cache behind them, bound it.  Here a CLUSTER of 8 work-groups on ONE XCD
- * (work-groups b with equal b % 8 share an XCD: the dispatcher deals them round-robin; checked against XCC_ID,
- * a mismatch is reported to the host) takes a spectrum through both stages:
- *   stage A  member m transforms residues [16 m, 16 m + 16) (k1h_stage_a's work item) and stores its 16 blocks
- *            into the cluster's 512 KiB intermediate;
- *   cluster barrier (arrive / wait counters in memory, relaxed agent-scope atomics: they and the plain stores
- *            meet in the XCD's L2, which is the coherence point of its CUs -- no L2 write-back, no invalidate);
- *   stage B  member m transforms offsets k in [64 m, 64 m + 64) (two of k1h_stage_b's work items side by side,
- *            one `a` per wave) reading the intermediate with L1-bypassing loads: L2 hits, the 32 clusters'
- *            16 MiB never has to leave the chip;
- *   the next spectrum's stage-A stores wait for every member's stage-B reads (second counter; the wait sits
- *            after stage A's arithmetic, so it is normally already satisfied).
- * The next spectrum's IQ is requested before the wait for stage A; window taps and the stage-B twiddles of a
- * thread never change (its residues / offsets are fixed) and stay in registers.  A cluster owns whole tiles of
- * spectra (live / max partials in registers across the tile).  Arithmetic: the same helpers in the same order
- * as the two-kernel form, hence the same bits. */
-static __device__ __forceinline__ v2f load_l2(const v2f *ptr)
-{
-	/* agent-scope relaxed load: global_load_dwordx2 ... sc1, misses the CU's L1 by construction */
-	const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr),
-	                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	v2f r;
-	r.x = __uint_as_float((uint32_t)u);
-	r.y = __uint_as_float((uint32_t)(u >> 32));
-	return r;
-}
+constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [residue 4][jj 16][a 16], rows padded to 17 */
+constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
+constexpr int kXLen   = 8 * kXaWave > kXbLen ? 8 * kXaWave : kXbLen;	/* the two exchanges share one region (a barrier separates their uses) */
+constexpr int kInRow  = 36;			/* staged input / window: [row m 256][residue 32] dwords, rows padded to 36 (conflict-free both ways) */
+constexpr size_t kK1hLds = ((size_t)kXLen + 16 * 15 + 32 * 15) * sizeof(float2) + (size_t)2 * 256 * kInRow * sizeof(float);
 
 template <bool HALF, bool WRITE_FFT>
-__global__ __launch_bounds__(1024, 4)
+__global__ __launch_bounds__(512, 2)
 void k1h_fused(const K1Params p)
 {
-	constexpr int N = 65536, QA = 16, M = 512, ROW = M + 1, KB = 64;
+	constexpr int N = 65536;
 	/* Every wait on another work-group is bounded (a poll is ~1 us: seconds, far beyond any legitimate wait): a protocol failure
 	 * ends the kernel with an error word the host turns into -EIO, it does not hang the GPU. */
 	constexpr uint32_t kSpinLimit = 4u << 20;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	v2f *l4 = reinterpret_cast<v2f *>(smem_raw);			/* stage B, after pass 4: [(i3, jj4)][k]; after pass 5 */
-	v2f *l5 = l4;
-	v2f *rows = reinterpret_cast<v2f *>(smem_raw);			/* stage A: 16 rows of 513 (aliases l4) */
-	v2f *tws = rows + QA * ROW;					/* stage A twiddles, passes p = 8, 64 */
-	v2f *t4 = tws + (8 + 64) * 7;					/* stage B twiddles of this member's 64 offsets: [j][k] */
-	v2f *t5 = t4 + 7 * KB;						/* [jj4][j][k] */
-	v2f *t6 = t5 + 8 * 7 * KB;					/* [m][k] */
+	v2f *xa_all = reinterpret_cast<v2f *>(smem_raw);		/* stage A: one private exchange region per wave ... */
+	v2f *xb = xa_all;						/* ... stage B: the work-group's exchange array, in the same memory */
+	v2f *twa_t = xa_all + kXLen;					/* pass-2 twiddles [k2 16][15] */
+	v2f *tw3_t = twa_t + 16 * 15;					/* pass-3 twiddles of this member's 32 offsets [32][15] */
+	float *winl = reinterpret_cast<float *>(tw3_t + 32 * 15);	/* window taps of this member's 32 residues [m 256][36] */
+	uint32_t *inb = reinterpret_cast<uint32_t *>(winl + 256 * kInRow);	/* fp16 IQ of the spectrum about to be transformed, same layout */
 
 	const int tid = threadIdx.x;
 	/* Cluster formation.  A work-group takes a ticket from the counter of the XCD it actually runs on (XCC_ID):
@@ -1570,65 +1401,110 @@ void k1h_fused(const K1Params p)
 	__syncthreads();
 	if (sh_ticket < 0)
 		return;
-	const int member = sh_ticket & 7;
-	const int gc = (int)xcc * 8 + (sh_ticket >> 3);			/* cluster: up to 8 per XCD */
+	/* (everything that is the same for the whole work-group is forced into SGPRs: addresses are then a scalar base plus ONE
+	 * 32-bit per-lane offset -- global_load / global_store ... s[base:base+1] -- instead of a 64-bit vector add per access) */
+	const int ticket = __builtin_amdgcn_readfirstlane(sh_ticket);
+	const int member = ticket & 7;
+	const int gc = (int)xcc * 8 + (ticket >> 3);			/* cluster: up to 8 per XCD */
 	uint32_t *c_a = p.sync + gc * 64;				/* stage A done */
 	uint32_t *c_t = p.sync + gc * 64 + 16;				/* (round << 20) | tile, published by member 0 */
 	uint32_t *c_b = p.sync + gc * 64 + 32;				/* stage B has read the intermediate */
-	v2f *w = reinterpret_cast<v2f *>(p.scratch) + (size_t)gc * N;
+	v2f *wint = reinterpret_cast<v2f *>(p.scratch) + (size_t)gc * N;	/* the cluster's intermediate: [offset / 32][residue][offset % 32] */
+	const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wint);
 
-	/* stage A geometry: residue q0 + (tid & 15), sub-FFT work-item tid >> 4; stage B: offset 64 member + (tid & 63),
-	 * a = tid >> 6 (one per wave).  The per-lane parts are re-derived from an opaque copy of tid inside the loops:
-	 * hoisted, the 64-bit addresses they feed cost more registers than the kernel has. */
-	const int q0 = member * QA;
-	const int a = __builtin_amdgcn_readfirstlane(tid >> 6);	/* 0..15 */
+	const int lane = tid & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
 	const float top = (float)(bk.nb - 1);
 
-	/* per-thread constants */
-	float wina[8];
+	/* ---- per-thread constants -------------------------------------------------------------------------------------
+	 * stage A: residue q = 32 member + 4 wave + (lane >> 4); pass-1 item a = lane & 15 reads m = a + 16 j; after the
+	 *          exchange the same lane is pass-2 item k2 = lane & 15 (twiddle index k2)
+	 * stage B: offset kk = 32 member + (tid & 31); pass-3 item a3 = tid >> 5 reads residues q = a3 + 16 j3 (twiddle
+	 *          index kk); after the exchange the same thread is pass-4 item jj3 = tid >> 5 (twiddle index kk + 256 jj3)
+	 *          and owns columns kk + 256 jj3 + 4096 jj4 */
+	const int sa = lane >> 4, ia = lane & 15;
+	const int qa = 32 * member + 4 * wv + sa;
+	const int kkl = tid & 31, ib = tid >> 5;
+	const int kk = 32 * member + kkl;
+	const int col0 = kk + 256 * ib;
+	const unsigned ucol0 = (unsigned)col0;				/* the one per-lane offset of every output access */
+	const unsigned wst0 = 8u * (unsigned)(qa * 32 + (ia ^ ((qa & 1) << 4)));		/* stage-A stores of even / odd jj (byte offsets) */
+	const unsigned wst1 = wst0 ^ 128u;
+	const unsigned wld = 8u * (unsigned)(ib * 32 + (kkl ^ ((ib & 1) << 4)));		/* stage-B loads */
+	const __amdgpu_buffer_rsrc_t rs_wf = make_rsrc(p.wf), rs_part = make_rsrc(p.partial);
+
+	v2f c16[4];
 #pragma unroll
-	for (int j = 0; j < 8; j++)
-		wina[j] = p.win[q0 + (tid & (QA - 1)) + 128 * ((tid >> 4) + 64 * j)];
-	/* twiddle tables of the block, loaded once (a thread's stage-B twiddles depend on (k, a) only) */
-	for (int e = tid; e < (8 + 64) * 7; e += 1024)
-		tws[e] = twg[e];
-	for (int e = tid; e < 7 * KB; e += 1024)
-		t4[e] = twg[p.tw_off[2] + (member * KB + (e & (KB - 1))) * 7 + (e >> 6)];
-	for (int e = tid; e < 8 * 7 * KB; e += 1024) {
-		const int kk = e & (KB - 1), j = (e >> 6) % 7, jj4 = (e >> 6) / 7;
-		t5[e] = twg[p.tw_off[3] + (member * KB + kk + 512 * jj4) * 7 + j];
-	}
-	for (int e = tid; e < 64 * KB; e += 1024)
-		t6[e] = twg[p.tw_off[4] + member * KB + (e & (KB - 1)) + 512 * (e >> 6)];
+	for (int i = 0; i < 4; i++)
+		c16[i] = twg[p.tw_off[0] + i];
+	for (int e = tid; e < 256 * 32; e += 512)			/* winl[m][c] = win[32 member + c + 256 m] */
+		winl[(e >> 5) * kInRow + (e & 31)] = p.win[32 * member + (e & 31) + 256 * (e >> 5)];
+	v2f tw4[15];
+#pragma unroll
+	for (int j = 0; j < 15; j++)
+		tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 15 + j];
+	for (int e = tid; e < 16 * 15; e += 512)
+		twa_t[e] = twg[p.tw_off[1] + e];
+	for (int e = tid; e < 32 * 15; e += 512)
+		tw3_t[e] = twg[p.tw_off[2] + (32 * member) * 15 + e];
 	__syncthreads();
+
+	v2f *xa = xa_all + wv * kXaWave;
+	const int ea_w = sa * 272 + ia;			/* + 17 jj : pass-1 outputs [residue][jj][a] */
+	const int ea_r = sa * 272 + ia * 17;		/* + j2    : pass-2 inputs of item k2 = ia */
+	const int eb_w = kkl * 257 + ib;		/* + 16 jj3: pass-3 outputs [offset][jj3][a3] */
+	const int eb_r = kkl * 257 + ib * 16;		/* + j4    : pass-4 inputs of item jj3 = ib */
 
 	uint32_t done = 0;						/* spectra this cluster has finished */
 	uint32_t round = 0;						/* tiles this cluster has taken */
 
 	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-	h2  xh[8];
-	v2f xf[8];
+	typedef u4v u4;
+	/* fp16 IQ: the work-group fetches its 32 residues of a spectrum as whole 128-byte runs -- thread tid takes the 16-byte pieces
+	 * g = tid + 512 k, k < 4 (row g >> 3, residues 4 (g & 7) .. + 3) -- and parks them in LDS, where each wave then finds the rows of
+	 * its four residues (a wave gathering its own 16-byte pieces straight from memory touches every line eight times over:
+	 * measured +205 us per frame against +37).  fp32 IQ (not a BASELINE configuration at this length) is gathered per lane. */
+	u4  xq[4];
+	v2f xf[HALF ? 1 : 16];
+	const int in_rd = ia * kInRow + 4 * wv + sa;			/* + 16 kInRow j: row m = ia + 16 j, residue 4 wave + sa */
 #pragma unroll
-	for (int j = 0; j < 8; j++) { xh[j] = h2{ (_Float16)0.25f, (_Float16)0.5f }; xf[j] = v2f{ 0.25f, 0.5f }; }	/* (only seen with dbg_k1h & 2) */
+	for (int k = 0; k < 4; k++)		/* (only seen with dbg_k1h & 2: noise-like, so that the epilogue takes its usual paths) */
+		xq[k] = u4{ 0x211f2a3du + 977u * tid + k, 0xa5212c11u + 131u * tid, 0x28e4a233u + 353u * tid + 7u * k, 0xa91e2540u + 89u * tid };
+#pragma unroll
+	for (int j = 0; j < (HALF ? 1 : 16); j++) xf[j] = v2f{ 0.01f * (float)(((tid * 37 + j * 11) & 63) - 32), 0.01f * (float)(((tid * 29 + j * 7) & 63) - 31) };
+	const uint32_t iq_vo = 4u * (256u * (unsigned)(tid >> 3) + 4u * (unsigned)(tid & 7));	/* this thread's 16-byte piece of a group of 64 rows */
 	auto fetch_iq = [&](int t) {
 		if (p.dbg_k1h & 2)
 			return;
-		int tl = tid;
-		asm volatile("" : "+v"(tl));
-		const int nb0 = q0 + (tl & (QA - 1)) + 128 * (tl >> 4);
+		if (HALF) {
+			const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + 32 * member);
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
-			const int n = nb0 + 128 * 64 * j;
-			if (HALF)
-				xh[j] = __builtin_nontemporal_load(reinterpret_cast<const h2 *>(p.iq) + (size_t)t * p.hop + n);
-			else
-				xf[j] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p.iq + (size_t)t * p.hop + n));
+			for (int k = 0; k < 4; k++)		/* piece g = tid + 512 k: row (tid >> 3) + 64 k */
+				xq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, iq_vo, 65536u * k, kAuxNT);
+		} else {
+			const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.iq + (size_t)t * p.hop);
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				xf[HALF ? 0 : j] = bld_v2f<kAuxNT>(rs, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
 		}
 	};
+	auto park_iq = [&]() {			/* registers -> LDS (the caller puts a barrier between this and the reads) */
+		if (HALF) {
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int g = tid + 512 * k;
+				*reinterpret_cast<u4 *>(inb + (g >> 3) * kInRow + 4 * (g & 7)) = xq[k];
+			}
+		}
+	};
+
+	uint32_t *bins_lo = p.bins;					/* [total / 4][N] dwords: 4 spectra x low 8 bits */
+	uint32_t *bins_hi = p.bins + (size_t)(p.total >> 2) * N;	/* [total / tile][N] dwords: bit u = 9th bit of the tile's spectrum u */
+
 	for (;;) {
 	/* member 0 claims the cluster's next tile */
 	if (tid == 0) {
@@ -1648,64 +1524,52 @@ void k1h_fused(const K1Params p)
 		sh_tile = (int)v;
 	}
 	__syncthreads();
-	const int tile = sh_tile;
+	const int tile = __builtin_amdgcn_readfirstlane(sh_tile);
 	round++;
 	if (tile >= ntiles)
 		break;
 	const int t0 = tile * p.tile;
 	fetch_iq(t0);
-	float live[8], vmax[8];
-	uint32_t pack[8];
+	park_iq();
+	__syncthreads();
+	float live[16], vmax[16];
+	uint32_t plo[16], phi[16];
 #pragma unroll
-	for (int c = 0; c < 8; c++) { live[c] = 0.0f; vmax[c] = vmax_init; pack[c] = 0; }
+	for (int c = 0; c < 16; c++) { live[c] = 0.0f; vmax[c] = vmax_init; plo[c] = 0; phi[c] = 0; }
 
 #pragma unroll 1
 	for (int u = 0; u < p.tile; u++) {
 		const int t = t0 + u;
-		v2f r[8];
-		int tl = tid;
-		asm volatile("" : "+v"(tl));
-		const int ql = tl & (QA - 1), ia = tl >> 4;
-		v2f *buf = rows + ql * ROW;
-		const int kl = tl & (KB - 1);
-		const int k = member * KB + kl;
+		v2f r[16];
 
-		/* ================= stage A: residues q0 .. q0 + 15 ================= */
+		/* ================= stage A: four residues per wave, no work-group barrier ================= */
 #pragma unroll
-		for (int j = 0; j < 8; j++) {
+		for (int j = 0; j < 16; j++) {
 			v2f xv;
-			if (HALF)
-				xv = v2f{ (float)xh[j].x, (float)xh[j].y };	/* v_cvt_f32_f16: exact */
-			else
-				xv = xf[j];
-			r[j] = v2f{ xv.x * wina[j], xv.y * wina[j] };		/* fft.cl:415-417 */
-		}
-		{
-			int pp = 1;
-#pragma unroll
-			for (int q8 = 0; q8 < 3; q8++) {
-				const int kk = ia & (pp - 1);
-				if (q8 > 0) {
-					const v2f *tw = tws + p.tw_off[q8 - 1] + kk * 7;
-#pragma unroll
-					for (int j = 1; j < 8; j++)
-						r[j] = c_mul(r[j], tw[j - 1]);
-				}
-				dft8(r, s12);
-				const int j0 = ((ia - kk) << 3) + kk;
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++)
-					buf[j0 + jj * pp] = r[R8_PERM(jj)];
-				__syncthreads();
-				if (q8 < 2) {
-#pragma unroll
-					for (int j = 0; j < 8; j++)
-						r[j] = buf[ia + 64 * j];
-					__syncthreads();
-				}
-				pp <<= 3;
+			if (HALF) {
+				const uint32_t raw = inb[in_rd + 16 * kInRow * j];
+				const h2 h = __builtin_bit_cast(h2, raw);
+				xv = v2f{ (float)h.x, (float)h.y };		/* v_cvt_f32_f16: exact */
+			} else {
+				xv = xf[HALF ? 0 : j];
 			}
+			const float wj = winl[in_rd + 16 * kInRow * j];
+			r[j] = v2f{ xv.x * wj, xv.y * wj };			/* window, fft.cl:415-417 */
 		}
+		dft16(r, s12, c16);						/* pass 1, p = 1: no twiddles */
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			xa[ea_w + 17 * jj] = r[R16_PERM(jj)];
+		wave_lds_sync();
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			r[j] = xa[ea_r + j];
+		wave_lds_sync();
+#pragma unroll
+		for (int j = 1; j < 16; j++)					/* pass 2, p = 16, k = ia */
+			r[j] = c_mul(r[j], twa_t[ia * 15 + j - 1]);
+		dft16(r, s12, c16);
+
 		/* every member has read the previous spectrum out of the intermediate? */
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
 			uint32_t spins = 0;
@@ -1716,19 +1580,19 @@ void k1h_fused(const K1Params p)
 		}
 		__syncthreads();
 		if (!(p.dbg_k1h & 8)) {
-			v2f *dst = w + (size_t)M * q0;
+			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
+			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
+			 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
 #pragma unroll
-			for (int c = 0; c < 8; c++) {
-				const int idx = tl + 1024 * c;
-				dst[idx] = rows[(idx >> 9) * ROW + (idx & (M - 1))];
-			}
+			for (int jj = 0; jj < 16; jj++)
+				bst_v2f<0>(r[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, 65536u * (jj >> 1));
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* this wave's blocks are in the L2 */
 		__syncthreads();
 		if (tid == 0)
 			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-		/* the tile's next spectrum, requested now */
+		/* the tile's next spectrum, requested now (it lands in registers during the cluster wait and pass 3) */
 		if (u + 1 < p.tile)
 			fetch_iq(t + 1);
 
@@ -1742,190 +1606,118 @@ void k1h_fused(const K1Params p)
 		__syncthreads();
 		asm volatile("" ::: "memory");
 
-		/* ================= stage B: offsets k = 64 member .. + 63 ================= */
+		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
 		if (!(p.dbg_k1h & 8)) {
+			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
 #pragma unroll
-			for (int j = 0; j < 8; j++)
-				r[j] = load_l2(w + 512 * (a + 16 * j) + k);
+			for (int j = 0; j < 16; j++)
+				r[j] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * j);
 		}
 #pragma unroll
-		for (int j = 1; j < 8; j++)
-			r[j] = c_mul(r[j], t4[(j - 1) * KB + kl]);
-		dft8(r, s12);
+		for (int j = 1; j < 16; j++)					/* pass 3, p = 256, k = kk */
+			r[j] = c_mul(r[j], tw3_t[kkl * 15 + j - 1]);
+		dft16(r, s12, c16);
 #pragma unroll
-		for (int jj = 0; jj < 8; jj++)
-			l4[(a * 8 + jj) * KB + kl] = r[R8_PERM(jj)];
+		for (int jj = 0; jj < 16; jj++)
+			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
 		__syncthreads();
 		if (tid == 0)							/* everybody's loads of the intermediate have landed */
 			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		done++;
-		{
-			const int i4 = a >> 3, jj4 = a & 7;
 #pragma unroll
-			for (int j = 0; j < 8; j++)
-				r[j] = l4[((i4 + 2 * j) * 8 + jj4) * KB + kl];
-#pragma unroll
-			for (int j = 1; j < 8; j++)
-				r[j] = c_mul(r[j], t5[(jj4 * 7 + j - 1) * KB + kl]);
-			dft8(r, s12);
-			__syncthreads();				/* l5 is l4: every read of pass 4's results is done */
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				l5[(i4 * 64 + jj * 8 + jj4) * KB + kl] = r[R8_PERM(jj)];
-		}
+		for (int j = 0; j < 16; j++)
+			r[j] = xb[eb_r + j];
+		/* the next spectrum's IQ goes into LDS; the barrier behind it also says that every read of the exchange array is done, so
+		 * that the next spectrum's stage A may write its (wave-private) exchange regions into the same memory */
+		if (u + 1 < p.tile)
+			park_iq();
 		__syncthreads();
-		v2f x[8];
 #pragma unroll
-		for (int c = 0; c < 4; c++) {
-			const int mm = 4 * a + c;
-			v2f va = l5[mm * KB + kl];
-			v2f vb = l5[(64 + mm) * KB + kl];
-			vb = c_mul(vb, t6[mm * KB + kl]);
-			DFT2(va, vb);
-			x[c] = va;
-			x[c + 4] = vb;
-		}
-		__syncthreads();					/* l4 / l5 become stage A's rows again */
+		for (int j = 1; j < 16; j++)					/* pass 4, p = 4096, k = kk + 256 ib */
+			r[j] = c_mul(r[j], tw4[j - 1]);
+		dft16(r, s12, c16);
 
 		if (WRITE_FFT) {
 #pragma unroll
-			for (int c = 0; c < 4; c++) {
-				const int jcol = k + 512 * (4 * a + c);
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol] = x[c];
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + jcol + N / 2] = x[c + 4];
-			}
+			for (int c = 0; c < 16; c++)
+				bst_v2f<0>(r[R16_PERM(c)], make_rsrc(reinterpret_cast<v2f *>(p.fft_out) + (size_t)t * N), 8u * ucol0, 32768u * c);
 		}
 
-		/* epilogue (display.cl:136,161-168), 16-bit bin indices */
-		float l2[8];
-		uint32_t bn[8];
-		uint32_t amb = 0;
-#pragma unroll
-		for (int c = 0; c < 8; c++) {
-			uint32_t ab;
-			const float rr = bin_fast(x[c].x, x[c].y, bk, &l2[c], &ab);
-			amb = amb > ab ? amb : ab;
-			bn[c] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
-		}
-		if (amb > __float_as_uint(bk.amb)) {
-#pragma unroll
-			for (int c = 0; c < 8; c++) {
-				const float v = __builtin_fmaf(bk.A, l2[c], bk.C);
-				const float rr = __builtin_rintf(v);
-				const float am = __builtin_fmaf(__builtin_fabsf(l2[c]), bk.kappa, __builtin_fabsf(v - rr));
-				if (!(am <= bk.amb)) {
-					float nl2;
-					bn[c] = bin_exact(x[c].x, x[c].y, l2[c], (int)bn[c], bk.thr, bk.nb, &nl2);
-					l2[c] = nl2;
-				}
-			}
-		}
+		/* epilogue (display.cl:136-150,161-168), 9-bit bin indices: low byte into the quad's dword, 9th bit into the tile's */
 		const bool store_row = (t >= p.wf_first) && !(p.dbg_k1h & 4);
-		float *wf_row = p.wf + (size_t)((p.wf_pos0 + t) & p.wf_mask) * N;
+		const uint32_t wf_so = (uint32_t)((p.wf_pos0 + t) & p.wf_mask) * (uint32_t)(N * 4);
+		const int sh8 = 8 * (u & 3);
 #pragma unroll
-		for (int c = 0; c < 8; c++) {
-			const int col = k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2);
-			pack[c] |= bn[c] << (16 * (u & 1));
-			live[c] = __builtin_fmaf(live[c], p.w, l2[c]);
-			vmax[c] = max_f32(vmax[c], l2[c]);
+		for (int c = 0; c < 16; c++) {
+			const v2f x = r[R16_PERM(c)];
+			float l2v; uint32_t ab;
+			const float rr = bin_fast(x.x, x.y, bk, &l2v, &ab);
+			uint32_t bn = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
+			if (ab > __float_as_uint(bk.amb)) {		/* rare: decided against the exact thresholds */
+				float nl2;
+				bn = bin_exact(x.x, x.y, l2v, (int)bn, bk.thr, bk.nb, &nl2);
+				l2v = nl2;
+			}
+			plo[c] |= (bn & 0xffu) << sh8;
+			phi[c] |= (bn >> 8) << u;
+			live[c] = __builtin_fmaf(live[c], p.w, l2v);
+			vmax[c] = max_f32(vmax[c], l2v);
 			/* rows and bin indices are streamed out non-temporally: plain stores allocate in the XCD's L2 and push the cluster's
-			 * intermediate out of it (PMC per 64 Mi-sample frame: WRITE_SIZE 904 -> 709 MiB, FETCH 332 -> 282 MiB; 357 -> 339 us) */
+			 * intermediate out of it */
 			if (store_row)
-				__builtin_nontemporal_store(l2[c] * F_HALF_LOG10_2, &wf_row[col]);
+				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, kAuxNT);
 		}
-		if ((u & 1) && !(p.dbg_k1h & 4)) {
-			uint32_t *dst = p.bins + (size_t)(t >> 1) * N;
+		if ((u & 3) == 3 && !(p.dbg_k1h & 4)) {
+			const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(bins_lo + (size_t)(t >> 2) * N);
 #pragma unroll
-			for (int c = 0; c < 8; c++) {
-				__builtin_nontemporal_store(pack[c], &dst[k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2)]);
-				pack[c] = 0;
+			for (int c = 0; c < 16; c++) {
+				__builtin_amdgcn_raw_buffer_store_b32(plo[c], rs_lo, 4u * ucol0, 16384u * c, kAuxNT);
+				plo[c] = 0;
 			}
 		}
 	}
-	float2 *pp2 = p.partial + (size_t)tile * N;
-	const int k = member * KB + (tid & (KB - 1));
+	if (!(p.dbg_k1h & 4)) {
+		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
 #pragma unroll
-	for (int c = 0; c < 8; c++)
-		pp2[k + 512 * (4 * a + (c & 3)) + (N / 2) * (c >> 2)] = make_float2(live[c] * F_HALF_LOG10_2,
-			(vmax[c] == vmax_init) ? -1000.0f : vmax[c] * F_HALF_LOG10_2);
+		for (int c = 0; c < 16; c++)
+			__builtin_amdgcn_raw_buffer_store_b32(phi[c], rs_hi, 4u * ucol0, 16384u * c, kAuxNT);
+	}
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+		bst_v2f<0>(v2f{ live[c] * F_HALF_LOG10_2, (vmax[c] == vmax_init) ? -1000.0f : vmax[c] * F_HALF_LOG10_2 },
+		           rs_part, 8u * ucol0, (uint32_t)tile * (uint32_t)(N * 8) + 32768u * c);
 	}
 }
 
 static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 {
-	constexpr size_t lds_a = ((size_t)16 * 513 + (8 + 64) * 7) * sizeof(float2);
-	constexpr int N = 65536;
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-		if (e == hipSuccess)
-			e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1h_stage_a<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-		if (e != hipSuccess)
-			return e;
-		attr_set = true;
-	}
-	if (p0.sync && p0.tile >= 2 && !(p0.tile & 1) && p0.total / p0.tile < (1 << 20)) {	/* (tile index: 20 bits of the claim word) */
-		/* fused form: 32 clusters of 8 work-groups, one work-group per CU */
-		constexpr size_t lds_f = ((size_t)16 * 513 + (8 + 64) * 7 + 7 * 64 + 8 * 7 * 64 + 64 * 64) * sizeof(float2);
-		static bool attr_f = false;
-		if (!attr_f) {
-			const void *fn[4] = { reinterpret_cast<const void *>(k1h_fused<false, false>), reinterpret_cast<const void *>(k1h_fused<true, false>),
-			                      reinterpret_cast<const void *>(k1h_fused<false, true>), reinterpret_cast<const void *>(k1h_fused<true, true>) };
-			for (int i = 0; i < 4; i++) {
-				const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
-				if (e != hipSuccess)
-					return e;
-			}
-			attr_f = true;
+	/* tiles of 4 .. 32 spectra (whole quads of low bytes, the 9th bits of a tile in one dword); tile index: 20 bits of the claim word */
+	if (!p0.sync || !p0.scratch || p0.tile < 4 || p0.tile > 32 || (p0.tile & 3) || p0.total % p0.tile || p0.total / p0.tile >= (1 << 20))
+		return hipErrorInvalidValue;
+	static bool attr_f = false;
+	if (!attr_f) {
+		const void *fn[4] = { reinterpret_cast<const void *>(k1h_fused<false, false>), reinterpret_cast<const void *>(k1h_fused<true, false>),
+		                      reinterpret_cast<const void *>(k1h_fused<false, true>), reinterpret_cast<const void *>(k1h_fused<true, true>) };
+		for (int i = 0; i < 4; i++) {
+			const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLds);
+			if (e != hipSuccess)
+				return e;
 		}
-		if (hipMemsetAsync(p0.sync, 0, 64 * 64 * sizeof(uint32_t), s) != hipSuccess)	/* the counters; not the error word behind them */
-			return hipErrorLaunchFailure;
-		if (p0.iq_half) {
-			if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<true, true>), dim3(256), dim3(1024), lds_f, s, p0);
-			else            hipLaunchKernelGGL((k1h_fused<true, false>), dim3(256), dim3(1024), lds_f, s, p0);
-		} else {
-			if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<false, true>), dim3(256), dim3(1024), lds_f, s, p0);
-			else            hipLaunchKernelGGL((k1h_fused<false, false>), dim3(256), dim3(1024), lds_f, s, p0);
-		}
-		return hipGetLastError();
+		attr_f = true;
 	}
-	/* Stage A and stage B alternate over groups of spectra whose intermediate (8 B per sample, fp32) fits the
-	 * Infinity Cache: the round trip between the stages then mostly stays on the die instead of costing 16 B of
-	 * HBM traffic per sample next to the 4 B of fp16 IQ.  Every group reuses the same scratch region. */
-	static const int group_env = [] { const char *e = getenv("FOSPHOR_AMD_K1H_GROUP"); return e ? atoi(e) : 0; }();
-	int group = group_env > 0 ? group_env : 128;			/* 128 x 512 KiB = 64 MiB of intermediate */
-	const int unit = p0.tile > 2 ? p0.tile : 2;			/* whole tiles, whole index dwords */
-	group -= group % unit;
-	if (group < unit) group = unit;
-	for (int s0 = 0; s0 < p0.total; s0 += group) {
-		K1Params p = p0;
-		p.total = (p0.total - s0 < group) ? p0.total - s0 : group;
-		p.iq = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(p0.iq) + (size_t)s0 * p0.hop * (p0.iq_half ? 4 : 8));
-		p.bins = p0.bins + (size_t)(s0 >> 1) * N;
-		p.partial = p0.partial + (size_t)(s0 / p0.tile) * N;
-		p.wf_pos0 = p0.wf_pos0 + s0;
-		p.wf_first = p0.wf_first - s0;
-		if (p.wf_first < 0) p.wf_first = 0;
-		if (p0.fft_out) p.fft_out = p0.fft_out + (size_t)s0 * N;
-		int blocks_a = p.total * 8;
-		if (blocks_a > 512) blocks_a = 512;			/* 2 work-groups of 64 KiB LDS per CU */
-		if (p.iq_half)
-			hipLaunchKernelGGL(k1h_stage_a<true>, dim3(blocks_a), dim3(1024), lds_a, s, p);
-		else
-			hipLaunchKernelGGL(k1h_stage_a<false>, dim3(blocks_a), dim3(1024), lds_a, s, p);
-		if (hipGetLastError() != hipSuccess)
-			return hipErrorLaunchFailure;
-		int blocks_b = (p.total / p.tile) * 16;
-		if (blocks_b > 512) blocks_b = 512;
-		if (p.fft_out)
-			hipLaunchKernelGGL(k1h_stage_b<true>, dim3(blocks_b), dim3(512), 0, s, p);
-		else
-			hipLaunchKernelGGL(k1h_stage_b<false>, dim3(blocks_b), dim3(512), 0, s, p);
-		if (hipGetLastError() != hipSuccess)
-			return hipErrorLaunchFailure;
+	if (hipMemsetAsync(p0.sync, 0, 64 * 64 * sizeof(uint32_t), s) != hipSuccess)	/* the counters; not the error word behind them */
+		return hipErrorLaunchFailure;
+	/* 32 clusters of 8 work-groups, one work-group (8 waves) per CU */
+	if (p0.iq_half) {
+		if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<true, true>), dim3(256), dim3(512), kK1hLds, s, p0);
+		else            hipLaunchKernelGGL((k1h_fused<true, false>), dim3(256), dim3(512), kK1hLds, s, p0);
+	} else {
+		if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<false, true>), dim3(256), dim3(512), kK1hLds, s, p0);
+		else            hipLaunchKernelGGL((k1h_fused<false, false>), dim3(256), dim3(512), kK1hLds, s, p0);
 	}
-	return hipSuccess;
+	return hipGetLastError();
 }
+
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s)
 {
@@ -2097,7 +1889,31 @@ void k2_count(const K2Params p)
 	/* bins: one dword = 4 consecutive spectra of one column (8-bit indices), or 2 (16-bit
 	 * indices, n_bins > 256 or N > 1024); a wave reads 256 contiguous bytes per row */
 	/* (uniform base pointer + 32-bit lane offsets: one address register per load in flight) */
-	if (p.bins16) {
+	if (p.bins9) {
+		/* 9-bit indices of the 65536-point kernel: a wave takes whole tiles -- one dword of 9th bits per lane and tile, then the
+		 * tile's (at most 8) dwords of low bytes, all requested before the first is used */
+		const uint32_t n = p.n, qpt = (uint32_t)p.tile >> 2, ntl = (uint32_t)(p.chunk / p.tile);
+		const uint32_t *lo = p.bins + (size_t)c * (p.chunk >> 2) * n + x0 + lane;
+		const uint32_t *hi = p.bins + (size_t)(p.total >> 2) * n + (size_t)c * ntl * n + x0 + lane;
+#pragma unroll 1
+		for (uint32_t tl = wv; tl < ntl; tl += NW) {
+			const uint32_t hv = hi[(size_t)tl * n];
+			uint32_t v[8];
+#pragma unroll
+			for (uint32_t u = 0; u < 8; u++)
+				v[u] = (u < qpt) ? lo[(size_t)(tl * qpt + u) * n] : 0u;
+#pragma unroll
+			for (uint32_t u = 0; u < 8; u++) {
+				if (u < qpt) {			/* uniform */
+					const uint32_t h4 = hv >> (4 * u);
+					atomicAdd(&h[(((v[u]      ) & 0xff) | ((h4 & 1u) << 8)) * 32 + hcol], inc);
+					atomicAdd(&h[(((v[u] >>  8) & 0xff) | ((h4 & 2u) << 7)) * 32 + hcol], inc);
+					atomicAdd(&h[(((v[u] >> 16) & 0xff) | ((h4 & 4u) << 6)) * 32 + hcol], inc);
+					atomicAdd(&h[(((v[u] >> 24)       ) | ((h4 & 8u) << 5)) * 32 + hcol], inc);
+				}
+			}
+		}
+	} else if (p.bins16) {
 		const uint32_t *src16 = p.bins + (size_t)c * (p.chunk >> 1) * p.n + x0;
 		const uint32_t nq16 = p.chunk >> 1, n = p.n;
 		uint32_t q = wv;
@@ -2243,7 +2059,7 @@ void k2_count(const K2Params p)
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
 	const size_t lds = (size_t)p.n_bins * 32 * sizeof(uint32_t);
-	if (p.bins16)
+	if (p.bins16 || p.bins9)
 		hipLaunchKernelGGL((k2_count<16, 4>), dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
 	else if (p.chunk > 1024)
 		hipLaunchKernelGGL((k2_count<4, 4>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);

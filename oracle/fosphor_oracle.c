@@ -140,6 +140,66 @@ static void o_pass_radix4(const cf *src, cf *dst, int n, int p)
 	}
 }
 
+/* ---- the radix-16 plan of N = 65536 (and 8192) --------------------------------------------------------------
+ * The reference has one FFT length, 1024 (fft.cl:397-466), and no butterfly wider than 8.  For the lengths BASELINE
+ * configs C3 / C5 name, no reference behaviour exists; the plan below is THIS BUILD'S OWN CHOICE,
+ * made for the GPU's memory hierarchy -- two radix-16 passes are a 256-point transform that one wavefront does on its
+ * own -- and restated here operation for operation so that the GPU kernels can be checked bit for bit.  It is built
+ * from the reference's pieces only: dft2 / dft8 (fft.cl:86-145), the constant rotations mul_p1q2 / p1q4 / p3q4
+ * (fft.cl:77-82), twiddle() with the reference's expression for the angle (fft.cl:61-69, 286-297), and the Stockham
+ * indexing of fft.cl:278-350 with 16 in the place of 8.
+ *
+ * dft16: decimation in frequency, one radix-2 stage in front of two dft8:
+ *     a[j] = r[j] + r[j + 8],  b[j] = (r[j] - r[j + 8]) * W16^j,  j < 8;   X[2m] = DFT8(a)[m],  X[2m + 1] = DFT8(b)[m]
+ * W16^j = twiddle(., j, -pi/8) for odd j (full complex products with the pinned sin / cos), the reference's constant
+ * rotations for j = 2, 4, 6.  Like o_dft8 it leaves X[jj] in r[bitrev4(jj)]. */
+static inline void o_dft16(cf *r)
+{
+	const float a16 = -ORACLE_PI_F / 8.0f;
+	int j;
+	for (j = 0; j < 8; j++)
+		o_dft2(&r[j], &r[j + 8]);
+	r[9]  = o_twiddle(r[9], 1, a16);
+	r[10] = o_mul_p1q4(r[10]);
+	r[11] = o_twiddle(r[11], 3, a16);
+	r[12] = o_mul_p1q2(r[12]);
+	r[13] = o_twiddle(r[13], 5, a16);
+	r[14] = o_mul_p3q4(r[14]);
+	r[15] = o_twiddle(r[15], 7, a16);
+	o_dft8(r);
+	o_dft8(r + 8);
+}
+
+/* One Stockham radix-16 pass: fft.cl:278-350 with t = N/16 work-items of 16 points, angle -pi k / (8 p). */
+static void o_pass_radix16(const cf *src, cf *dst, int n, int p, int tw)
+{
+	const int t = n >> 4;
+	/* X[jj] sits in r[8 (jj & 1) + perm8[jj >> 1]] = r[bitrev4(jj)] */
+	static const int perm[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
+	int i, j;
+
+	for (i = 0; i < t; i++) {
+		cf r[16];
+		int k = i & (p - 1);
+		int j0;
+
+		for (j = 0; j < 16; j++)
+			r[j] = src[i + j * t];
+
+		if (tw) {
+			float alpha = -ORACLE_PI_F * (float)k / (float)(8 * p);
+			for (j = 1; j < 16; j++)
+				r[j] = o_twiddle(r[j], j, alpha);
+		}
+
+		o_dft16(r);
+
+		j0 = ((i - k) << 4) + k;
+		for (j = 0; j < 16; j++)
+			dst[j0 + j * p] = r[perm[j]];
+	}
+}
+
 /* Final radix-2 pass: fft.cl:428-458 (p = N/2, k = i, t = N/2) */
 static void o_pass_radix2(const cf *src, cf *dst, int n)
 {
@@ -171,6 +231,16 @@ static void o_fft_one(int log2n, const cf *in, cf *out, const float *win, cf *sc
 	}
 
 	p = 1;
+	if (log2n == 16) {
+		/* this build's plan for N = 65536: four radix-16 passes, p = 1, 16, 256, 4096 (see o_dft16) */
+		for (done = 0; done < 16; done += 4) {
+			o_pass_radix16(a, b, n, p, p > 1);
+			tmp = a; a = b; b = tmp;
+			p <<= 4;
+		}
+		memcpy(out, a, sizeof(cf) * (size_t)n);
+		return;
+	}
 	for (done = 0; done + 3 <= log2n; done += 3) {
 		o_pass_radix8(a, b, n, p, p > 1);
 		tmp = a; a = b; b = tmp;
