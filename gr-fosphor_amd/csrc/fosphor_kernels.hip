@@ -137,8 +137,9 @@ static __device__ __forceinline__ void wave_lds_sync()
  * thr[b] for b in [1, nb) = smallest double s with oracle_bin(s) >= b; thr[0] = -1;
  * thr[nb] = smallest s whose hypot overflows float (-> non-finite -> bin 0,
  * fosphor_portable_math.h fpm_bin_from_pwr). */
+template <typename ThrPtr>		/* const double * (memory) or an LDS pointer (the 65536-point kernel's copy of the table) */
 static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float l2_fast, int guess,
-                                                      const double *__restrict__ thr, int nb, float *l2_out)
+                                                      ThrPtr thr, int nb, float *l2_out)
 {
 	const double xr = (double)re, xi = (double)im;
 	const double sd = __builtin_fma(xr, xr, xi * xi);
@@ -1338,8 +1339,10 @@ static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_
 constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [residue 4][jj 16][a 16], rows padded to 17 */
 constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
 constexpr int kXLen   = 8 * kXaWave > kXbLen ? 8 * kXaWave : kXbLen;	/* the two exchanges share one region (a barrier separates their uses) */
-constexpr int kInRow  = 36;			/* staged input / window: [row m 256][residue 32] dwords, rows padded to 36 (conflict-free both ways) */
-constexpr size_t kK1hLds = ((size_t)kXLen + 16 * 15 + 32 * 15) * sizeof(float2) + (size_t)2 * 256 * kInRow * sizeof(float);
+constexpr int kInLen  = 256 * 32;		/* staged fp16 input of one spectrum: [row m 256][residue 32] dwords, 16-byte pieces permuted inside a row */
+constexpr int kThrMax  = 520;			/* exact-bin thresholds kept in LDS (n_bins + 1 <= 513 doubles) */
+constexpr size_t kK1hLds = ((size_t)kXLen + 16 * 15 + 32 * 15) * sizeof(float2) + (size_t)2 * kInLen * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
+						/* (exchange, two twiddle tables, staged input + window taps in the same layout, thresholds) */
 
 template <bool HALF, bool WRITE_FFT>
 __global__ __launch_bounds__(512, 2)
@@ -1354,8 +1357,12 @@ void k1h_fused(const K1Params p)
 	v2f *xb = xa_all;						/* ... stage B: the work-group's exchange array, in the same memory */
 	v2f *twa_t = xa_all + kXLen;					/* pass-2 twiddles [k2 16][15] */
 	v2f *tw3_t = twa_t + 16 * 15;					/* pass-3 twiddles of this member's 32 offsets [32][15] */
-	float *winl = reinterpret_cast<float *>(tw3_t + 32 * 15);	/* window taps of this member's 32 residues [m 256][36] */
-	uint32_t *inb = reinterpret_cast<uint32_t *>(winl + 256 * kInRow);	/* fp16 IQ of the spectrum about to be transformed, same layout */
+	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + 32 * 15);	/* fp16 IQ of the next two spectra (two buffers of kInLen dwords) */
+	/* the exact-bin thresholds: the rare path that consults them must not wait for the loads and stores in flight (LDS reads have
+	 * their own counter) */
+	typedef const __attribute__((address_space(3))) double *lds_cdp;
+	double *thr_g = reinterpret_cast<double *>(inb + 2 * kInLen);
+	const lds_cdp thr_l = (lds_cdp)thr_g;
 
 	const int tid = threadIdx.x;
 	/* Cluster formation.  A work-group takes a ticket from the counter of the XCD it actually runs on (XCC_ID):
@@ -1441,12 +1448,16 @@ void k1h_fused(const K1Params p)
 #pragma unroll
 	for (int i = 0; i < 4; i++)
 		c16[i] = twg[p.tw_off[0] + i];
-	for (int e = tid; e < 256 * 32; e += 512)			/* winl[m][c] = win[32 member + c + 256 m] */
-		winl[(e >> 5) * kInRow + (e & 31)] = p.win[32 * member + (e & 31) + 256 * (e >> 5)];
+	float wina[16];							/* the 16 window taps of this thread's pass-1 item */
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		wina[j] = p.win[qa + 256 * (ia + 16 * j)];
 	v2f tw4[15];
 #pragma unroll
 	for (int j = 0; j < 15; j++)
 		tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 15 + j];
+	for (int e = tid; e <= p.n_bins && e < kThrMax; e += 512)
+		thr_g[e] = p.thr[e];
 	for (int e = tid; e < 16 * 15; e += 512)
 		twa_t[e] = twg[p.tw_off[1] + e];
 	for (int e = tid; e < 32 * 15; e += 512)
@@ -1463,43 +1474,73 @@ void k1h_fused(const K1Params p)
 	uint32_t round = 0;						/* tiles this cluster has taken */
 
 	typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-	typedef u4v u4;
-	/* fp16 IQ: the work-group fetches its 32 residues of a spectrum as whole 128-byte runs -- thread tid takes the 16-byte pieces
-	 * g = tid + 512 k, k < 4 (row g >> 3, residues 4 (g & 7) .. + 3) -- and parks them in LDS, where each wave then finds the rows of
-	 * its four residues (a wave gathering its own 16-byte pieces straight from memory touches every line eight times over:
-	 * measured +205 us per frame against +37).  fp32 IQ (not a BASELINE configuration at this length) is gathered per lane. */
-	u4  xq[4];
-	v2f xf[HALF ? 1 : 16];
-	const int in_rd = ia * kInRow + 4 * wv + sa;			/* + 16 kInRow j: row m = ia + 16 j, residue 4 wave + sa */
-#pragma unroll
-	for (int k = 0; k < 4; k++)		/* (only seen with dbg_k1h & 2: noise-like, so that the epilogue takes its usual paths) */
-		xq[k] = u4{ 0x211f2a3du + 977u * tid + k, 0xa5212c11u + 131u * tid, 0x28e4a233u + 353u * tid + 7u * k, 0xa91e2540u + 89u * tid };
-#pragma unroll
-	for (int j = 0; j < (HALF ? 1 : 16); j++) xf[j] = v2f{ 0.01f * (float)(((tid * 37 + j * 11) & 63) - 32), 0.01f * (float)(((tid * 29 + j * 7) & 63) - 31) };
-	const uint32_t iq_vo = 4u * (256u * (unsigned)(tid >> 3) + 4u * (unsigned)(tid & 7));	/* this thread's 16-byte piece of a group of 64 rows */
-	auto fetch_iq = [&](int t) {
-		if (p.dbg_k1h & 2)
+	/* fp16 IQ: the work-group fetches its 32 residues of a spectrum as whole 128-byte runs STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds:
+	 * no staging registers, no ds_write pass) -- one wave-instruction lands 64 x 16 B = 8 rows x 128 B back to back, so rows cannot be
+	 * padded; the 16-byte piece pc of row m sits at slot 8 m + (pc ^ (m & 7)) instead (the permutation is applied to the per-lane SOURCE
+	 * address and again to the read address; a wave's reads meet two-way conflicts at most).  A wave then finds the rows of its four
+	 * residues in LDS (a wave gathering its own 16-byte pieces straight from memory touches every line eight times over: measured
+	 * +205 us per frame against +37).  Two buffers: spectrum u of a tile in buffer u & 1.
+	 * fp32 IQ (not a BASELINE configuration at this length) is gathered per lane where it is used. */
+	const uint32_t iq_vo = 1024u * (unsigned)(lane >> 3) + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
+	const int in_rd  = ia * 32 + ((wv ^ (ia & 7)) << 2) + sa;	/* + 512 j: row m = ia + 16 j, residue 4 wave + sa (dwords) */
+	const uint32_t inb_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)inb;
+	if (p.dbg_k1h & 2)			/* (measurement only: noise-like input that is never loaded) */
+		for (int e = tid; e < 2 * kInLen; e += 512)
+			inb[e] = ((0x211fu + 977u * e) & 0x3fffu) | 0x20000000u | (((0x2c11u + 131u * e) & 0x3fffu) << 16) | ((e & 1u) << 15) | ((e & 2u) << 30);
+	auto fetch_iq = [&](int t, int buf) {		/* row groups g = wave, wave + 7, ... < 32 (8 rows each) into buffer `buf`; the last wave
+							 * requests nothing: it polls the cluster counters, and a poll returns behind whatever
+							 * its wave has in flight */
+		if (!HALF || (p.dbg_k1h & 2) || wv == 7)
 			return;
-		if (HALF) {
-			const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + 32 * member);
-#pragma unroll
-			for (int k = 0; k < 4; k++)		/* piece g = tid + 512 k: row (tid >> 3) + 64 k */
-				xq[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, iq_vo, 65536u * k, kAuxNT);
-		} else {
-			const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.iq + (size_t)t * p.hop);
-#pragma unroll
-			for (int j = 0; j < 16; j++)
-				xf[HALF ? 0 : j] = bld_v2f<kAuxNT>(rs, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
+		if (p.dbg_k1h & 32) t = gc;	/* (measurement only: the same rows again and again) */
+		/* global_load_lds_dwordx4 by hand: the compiler parks every LDS read and every __syncthreads() that follows an LDS-DMA it
+		 * knows about behind s_waitcnt vmcnt(0) -- the request would be waited for at the very next barrier instead of an iteration
+		 * later.  Whoever reads the buffer is behind an explicit `s_waitcnt vmcnt(..)` of the requesting wave and a barrier. */
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + 32 * member;
+#pragma unroll 1
+		for (int g = wv; g < 32; g += 7) {
+			const uint32_t *sk = src + 2048 * g;						/* 8 rows of 1 KiB */
+			const uint32_t la = inb_lds + 4u * (unsigned)(buf * kInLen + 256 * g);
+			uint32_t keep;
+			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+			             : "=&s"(keep) : "v"(iq_vo), "s"(sk), "s"(la) : "memory");
 		}
 	};
-	auto park_iq = [&]() {			/* registers -> LDS (the caller puts a barrier between this and the reads) */
-		if (HALF) {
+
+	v2f ra[16];				/* stage A of the spectrum AFTER the one stage B is working on */
+	/* pass 1 (p = 1: no twiddles) of spectrum t and the 16 x 16 transpose inside the wave */
+	auto stage_a1 = [&](int t, int buf) {
+		const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.iq + (size_t)t * p.hop);
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				const int g = tid + 512 * k;
-				*reinterpret_cast<u4 *>(inb + (g >> 3) * kInRow + 4 * (g & 7)) = xq[k];
+		for (int j = 0; j < 16; j++) {
+			v2f xv;
+			if (HALF) {
+				const uint32_t raw = inb[buf * kInLen + in_rd + 512 * j];
+				const h2 h = __builtin_bit_cast(h2, raw);
+				xv = v2f{ (float)h.x, (float)h.y };		/* v_cvt_f32_f16: exact */
+			} else if (p.dbg_k1h & 2) {
+				xv = v2f{ 0.01f * (float)(((tid * 37 + j * 11) & 63) - 32), 0.01f * (float)(((tid * 29 + j * 7) & 63) - 31) };
+			} else {
+				xv = bld_v2f<kAuxNT>(rs_f, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
 			}
+			ra[j] = v2f{ xv.x * wina[j], xv.y * wina[j] };		/* window, fft.cl:415-417 */
 		}
+		dft16(ra, s12, c16);
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			xa[ea_w + 17 * jj] = ra[R16_PERM(jj)];
+		wave_lds_sync();
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			ra[j] = xa[ea_r + j];
+		wave_lds_sync();
+	};
+	/* pass 2, p = 16, k = ia */
+	auto stage_a2 = [&]() {
+#pragma unroll
+		for (int j = 1; j < 16; j++)
+			ra[j] = c_mul(ra[j], twa_t[ia * 15 + j - 1]);
+		dft16(ra, s12, c16);
 	};
 
 	uint32_t *bins_lo = p.bins;					/* [total / 4][N] dwords: 4 spectra x low 8 bits */
@@ -1523,78 +1564,55 @@ void k1h_fused(const K1Params p)
 		}
 		sh_tile = (int)v;
 	}
-	__syncthreads();
+	__syncthreads();				/* (also: every read of the exchange array by the previous tile's last spectrum is done) */
 	const int tile = __builtin_amdgcn_readfirstlane(sh_tile);
 	round++;
 	if (tile >= ntiles)
 		break;
 	const int t0 = tile * p.tile;
-	fetch_iq(t0);
-	park_iq();
-	__syncthreads();
+	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
+	fetch_iq(t0, 0);
+	if (1 < p.tile)
+		fetch_iq(t0 + 1, 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	wg_barrier_lds();
+	stage_a1(t0, 0);
+	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
+	if (2 < p.tile)
+		fetch_iq(t0 + 2, 0);
+	stage_a2();
 	float live[16], vmax[16];
 	uint32_t plo[16], phi[16];
 #pragma unroll
 	for (int c = 0; c < 16; c++) { live[c] = 0.0f; vmax[c] = vmax_init; plo[c] = 0; phi[c] = 0; }
 
+	/* The loop is skewed: while spectrum u's blocks travel to the L2 (stores), to the other members (cluster wait) and back (loads),
+	 * the same threads run stage A of spectrum u + 1 -- its first pass between the stores and the arrival at the cluster barrier,
+	 * its second between the loads of the intermediate and their use. */
 #pragma unroll 1
 	for (int u = 0; u < p.tile; u++) {
 		const int t = t0 + u;
-		v2f r[16];
+		const bool more = (u + 1 < p.tile);
 
-		/* ================= stage A: four residues per wave, no work-group barrier ================= */
-#pragma unroll
-		for (int j = 0; j < 16; j++) {
-			v2f xv;
-			if (HALF) {
-				const uint32_t raw = inb[in_rd + 16 * kInRow * j];
-				const h2 h = __builtin_bit_cast(h2, raw);
-				xv = v2f{ (float)h.x, (float)h.y };		/* v_cvt_f32_f16: exact */
-			} else {
-				xv = xf[HALF ? 0 : j];
-			}
-			const float wj = winl[in_rd + 16 * kInRow * j];
-			r[j] = v2f{ xv.x * wj, xv.y * wj };			/* window, fft.cl:415-417 */
-		}
-		dft16(r, s12, c16);						/* pass 1, p = 1: no twiddles */
-#pragma unroll
-		for (int jj = 0; jj < 16; jj++)
-			xa[ea_w + 17 * jj] = r[R16_PERM(jj)];
-		wave_lds_sync();
-#pragma unroll
-		for (int j = 0; j < 16; j++)
-			r[j] = xa[ea_r + j];
-		wave_lds_sync();
-#pragma unroll
-		for (int j = 1; j < 16; j++)					/* pass 2, p = 16, k = ia */
-			r[j] = c_mul(r[j], twa_t[ia * 15 + j - 1]);
-		dft16(r, s12, c16);
-
-		/* every member has read the previous spectrum out of the intermediate? */
-		if (tid == 0 && !(p.dbg_k1h & 1)) {
-			uint32_t spins = 0;
-			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
-				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
-				__builtin_amdgcn_s_sleep(1);
-			}
-		}
-		__syncthreads();
+		/* (every member has read the previous spectrum out of the intermediate: the last wave looked before its epilogue)
+		 * every read of the stage-B exchange array is done -- stage A writes the same memory */
+		wg_barrier_lds();
 		if (!(p.dbg_k1h & 8)) {
 			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
 			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
 			 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
 #pragma unroll
 			for (int jj = 0; jj < 16; jj++)
-				bst_v2f<0>(r[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, 65536u * (jj >> 1));
+				bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, 65536u * (jj >> 1));
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* this wave's blocks are in the L2 */
-		__syncthreads();
+		if (more)
+			stage_a1(t + 1, (u + 1) & 1);			/* (while the stores travel) */
+		/* this wave's blocks are in the L2 (and the input rows it requested most of an iteration ago in LDS) */
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		wg_barrier_lds();
 		if (tid == 0)
 			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-		/* the tile's next spectrum, requested now (it lands in registers during the cluster wait and pass 3) */
-		if (u + 1 < p.tile)
-			fetch_iq(t + 1);
 
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
 			uint32_t spins = 0;
@@ -1603,39 +1621,56 @@ void k1h_fused(const K1Params p)
 				__builtin_amdgcn_s_sleep(1);
 			}
 		}
-		__syncthreads();
+		wg_barrier_lds();
 		asm volatile("" ::: "memory");
 
 		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
+		v2f r[16];
 		if (!(p.dbg_k1h & 8)) {
 			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
 #pragma unroll
 			for (int j = 0; j < 16; j++)
 				r[j] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * j);
+		} else {
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				r[j] = ra[j];
 		}
+		if (more)
+			stage_a2();					/* (while the loads travel) */
 #pragma unroll
 		for (int j = 1; j < 16; j++)					/* pass 3, p = 256, k = kk */
 			r[j] = c_mul(r[j], tw3_t[kkl * 15 + j - 1]);
+		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (two barriers ago); it is
+		 * waited for by the `vmcnt(0)` of the NEXT iteration.  Requested only now that the loads of the intermediate have been used:
+		 * loads return in order, and these come from HBM */
+		if (u + 3 < p.tile)
+			fetch_iq(t + 3, (u + 1) & 1);
 		dft16(r, s12, c16);
 #pragma unroll
 		for (int jj = 0; jj < 16; jj++)
 			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
-		__syncthreads();
+		wg_barrier_lds();
 		if (tid == 0)							/* everybody's loads of the intermediate have landed */
 			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		done++;
 #pragma unroll
 		for (int j = 0; j < 16; j++)
 			r[j] = xb[eb_r + j];
-		/* the next spectrum's IQ goes into LDS; the barrier behind it also says that every read of the exchange array is done, so
-		 * that the next spectrum's stage A may write its (wave-private) exchange regions into the same memory */
-		if (u + 1 < p.tile)
-			park_iq();
-		__syncthreads();
 #pragma unroll
 		for (int j = 1; j < 16; j++)					/* pass 4, p = 4096, k = kk + 256 ib */
 			r[j] = c_mul(r[j], tw4[j - 1]);
 		dft16(r, s12, c16);
+
+		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
+		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them */
+		if (tid == 448 && !(p.dbg_k1h & 1)) {
+			uint32_t spins = 0;
+			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
 
 		if (WRITE_FFT) {
 #pragma unroll
@@ -1653,9 +1688,9 @@ void k1h_fused(const K1Params p)
 			float l2v; uint32_t ab;
 			const float rr = bin_fast(x.x, x.y, bk, &l2v, &ab);
 			uint32_t bn = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
-			if (ab > __float_as_uint(bk.amb)) {		/* rare: decided against the exact thresholds */
+			if (ab > __float_as_uint(bk.amb) && !(p.dbg_k1h & 16)) {		/* rare: decided against the exact thresholds */
 				float nl2;
-				bn = bin_exact(x.x, x.y, l2v, (int)bn, bk.thr, bk.nb, &nl2);
+				bn = bin_exact(x.x, x.y, l2v, (int)bn, thr_l, bk.nb, &nl2);
 				l2v = nl2;
 			}
 			plo[c] |= (bn & 0xffu) << sh8;
