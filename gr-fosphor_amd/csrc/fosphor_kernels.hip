@@ -271,6 +271,9 @@ void k1_fft_bin(const K1Params p)
 	__shared__ v2f   lds[4][kN];			/* 8 KiB exchange slab per wave */
 	__shared__ v2f   tw4_tab[512];			/* pass-4 twiddles, shared by the block */
 	__shared__ float win_tab[kN];			/* window, shared by the block */
+	/* exact-bin thresholds (n_bins <= 256 in this kernel): the rare path that consults them would otherwise wait for its two table
+	 * loads BEHIND the next spectrum's IQ, already requested from HBM -- loads return in order */
+	__shared__ double thr_tab[264];
 #if K1_DBG_EPI & 32
 	__shared__ uint32_t dbg_cnt[256 * 32];		/* probe: the counter image of a 64-column slab */
 #endif
@@ -289,6 +292,8 @@ void k1_fft_bin(const K1Params p)
 		win_tab[i] = p.win[i];
 	for (int i = threadIdx.x; i < 512; i += 256)
 		tw4_tab[i] = twg[kTw4Off + i];
+	for (int i = threadIdx.x; i <= p.n_bins && i < 264; i += 256)
+		thr_tab[i] = p.thr[i];
 	__syncthreads();				/* the only block-wide barrier */
 
 	if (tile >= ntiles)
@@ -470,6 +475,9 @@ void k1_fft_bin(const K1Params p)
 				else
 					pack[m] ^= __float_as_uint(r);
 			}
+#ifndef K1_THR_LDS
+#define K1_THR_LDS 1			/* 0: the thresholds read from memory (A/B builds) */
+#endif
 #ifndef K1_DBG_NO_EXACT
 #define K1_DBG_NO_EXACT 0		/* measurement only: 1 drops the exact path (wrong bins on near-ties) */
 #endif
@@ -484,7 +492,12 @@ void k1_fft_bin(const K1Params p)
 					if (!(a <= bk.amb)) {
 						const int guess = (int)__builtin_amdgcn_fmed3f(r, 0.0f, top);
 						float nl2;
+#if K1_THR_LDS
+						const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess,
+						                               (const __attribute__((address_space(3))) double *)thr_tab, bk.nb, &nl2);
+#else
 						const uint32_t nbn = bin_exact(x[m].x, x[m].y, l2[m], guess, bk.thr, bk.nb, &nl2);
+#endif
 						pack[m] = (pack[m] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
 						l2[m] = nl2;
 					}
