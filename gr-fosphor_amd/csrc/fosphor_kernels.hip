@@ -137,35 +137,103 @@ static __device__ __forceinline__ void wave_lds_sync()
  * thr[b] for b in [1, nb) = smallest double s with oracle_bin(s) >= b; thr[0] = -1;
  * thr[nb] = smallest s whose hypot overflows float (-> non-finite -> bin 0,
  * fosphor_portable_math.h fpm_bin_from_pwr). */
-template <typename ThrPtr>		/* const double * (memory) or an LDS pointer (the 65536-point kernel's copy of the table) */
+/* Where the exact path finds its thresholds.  It runs for ~1.5e-4 of the samples, i.e. in every sixth wave-spectrum, and a table load
+ * through the vector memory path returns IN ORDER behind whatever the wave has in flight -- the next spectrum's IQ, requested from HBM
+ * before the epilogue: measured on the 8192-point kernel, whose eight waves then all wait at the next barrier, 369 -> 318 us per launch
+ * with the path removed.  Two ways around it:
+ *   an LDS copy of the table (address_space(3) pointer: ds_read, its own counter) where the kernel has 2-4 KiB of LDS to spare;
+ *   ThrScalar: the table entries fetched by the SCALAR unit (s_load_dwordx4 through the scalar cache, counted by lgkmcnt, out of order
+ *   with the vector loads), one active lane after the other (usually there is exactly one). */
+struct ThrScalar { const double *p; };
+typedef uint32_t thr_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t thr_u2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ double thr_mk(uint32_t lo, uint32_t hi)
+{
+	return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+/* t0 = thr[i], t1 = thr[i + 1] for every active lane */
+template <typename ThrPtr>
+static __device__ __forceinline__ void thr_pair(ThrPtr thr, int i, double *t0, double *t1)
+{
+	*t0 = thr[i];
+	*t1 = thr[i + 1];
+}
+template <>
+__device__ __forceinline__ void thr_pair<ThrScalar>(ThrScalar thr, int i, double *t0, double *t1)
+{
+	double a = 0.0, b = 0.0;
+	unsigned long long todo = __builtin_amdgcn_ballot_w64(true);		/* the active lanes */
+	while (todo) {
+		const int l = __builtin_ctzll(todo);
+		const int g = __builtin_amdgcn_readlane(i, l);
+		thr_u4 v;
+		asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(thr.p + g) : "memory");
+		const bool mine = (i == g);
+		if (mine) { a = thr_mk(v.x, v.y); b = thr_mk(v.z, v.w); }
+		todo &= ~__builtin_amdgcn_ballot_w64(mine);
+	}
+	*t0 = a; *t1 = b;
+}
+template <typename ThrPtr>
+static __device__ __forceinline__ double thr_one(ThrPtr thr, int i)
+{
+	return thr[i];
+}
+template <>
+__device__ __forceinline__ double thr_one<ThrScalar>(ThrScalar thr, int i)
+{
+	double a = 0.0;
+	unsigned long long todo = __builtin_amdgcn_ballot_w64(true);
+	while (todo) {
+		const int l = __builtin_ctzll(todo);
+		const int g = __builtin_amdgcn_readlane(i, l);
+		thr_u2 v;
+		asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(thr.p + g) : "memory");
+		const bool mine = (i == g);
+		if (mine) a = thr_mk(v.x, v.y);
+		todo &= ~__builtin_amdgcn_ballot_w64(mine);
+	}
+	return a;
+}
+
+template <typename ThrPtr>		/* const double * (vector loads), an LDS pointer (a kernel's own copy of the table), or ThrScalar */
 static __device__ __forceinline__ uint32_t bin_exact(float re, float im, float l2_fast, int guess,
                                                       ThrPtr thr, int nb, float *l2_out)
 {
+#ifdef K1_DBG_EXACT_BODY		/* measurement only: 1 = the branch with an empty body, 2 = the arithmetic without the table */
+	if (K1_DBG_EXACT_BODY == 1) { *l2_out = l2_fast; asm volatile("s_nop 0"); return (uint32_t)guess; }
+#endif
 	const double xr = (double)re, xi = (double)im;
 	const double sd = __builtin_fma(xr, xr, xi * xi);
 	const float  sf = (float)sd;
 	int bin;
 
+#ifdef K1_DBG_EXACT_BODY
+	if (K1_DBG_EXACT_BODY == 2) { *l2_out = l2_fast; return (uint32_t)(guess - (sd < 1.0 ? 1 : 0) + (sd >= 3.0 ? 1 : 0)) & 255u; }
+#endif
 	if (sf >= 1e-30f && sf <= 1e30f) {
 		/* the guess is within one bin of the truth */
-		bin = guess - (sd < thr[guess] ? 1 : 0) + (sd >= thr[guess + 1] ? 1 : 0);
+		double t0, t1;
+		thr_pair(thr, guess, &t0, &t1);
+		bin = guess - (sd < t0 ? 1 : 0) + (sd >= t1 ? 1 : 0);
 		*l2_out = l2_fast;
 	} else {
 		/* zero, denormal, huge, inf or NaN: full search, and a log-power that does not
 		 * depend on |X|^2 fitting a float: split sd = m * 2^e, m in [1,2) */
 		int lo = 0, hi = nb;		/* invariant: sd >= thr[lo] (thr[0] = -1); sd < thr[hi] or hi == nb */
-		if (sd >= thr[nb]) {
+		const double t_top = thr_one(thr, nb);
+		if (sd >= t_top) {
 			bin = nb;
 		} else if (!(sd >= 0.0)) {
 			bin = 0;		/* NaN */
 		} else {
 			while (hi - lo > 1) {
 				int mid = (lo + hi) >> 1;
-				if (sd >= thr[mid]) lo = mid; else hi = mid;
+				if (sd >= thr_one(thr, mid)) lo = mid; else hi = mid;
 			}
 			bin = lo;
 		}
-		if (__builtin_isinf(re) || __builtin_isinf(im) || sd >= thr[nb]) {
+		if (__builtin_isinf(re) || __builtin_isinf(im) || sd >= t_top) {
 			*l2_out = __builtin_inff();		/* hypot(inf, anything) = inf; float hypot overflow */
 		} else if (sd == 0.0) {
 			*l2_out = -__builtin_inff();		/* log10(0) */
@@ -199,6 +267,12 @@ struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
 #define K1_DBG_EPI 0		/* measurement only (wrong results): 1 no v_log_f32, 2 no ambiguity measure, 4 no live / max update, 8 no bin byte,
 				 * 16 no bin-index stores, 32 sixteen LDS atomics per spectrum on a dummy counter array (what counting inside K1
 				 * would issue): the probe builds of profiles/r04_ceiling.md (tools/r04_ceiling_build.sh) */
+#endif
+#ifndef K1_THR_LDS
+#define K1_THR_LDS 1			/* 0: the N = 1024 kernel reads the thresholds from memory (A/B builds) */
+#endif
+#ifndef K1_DBG_NO_EXACT
+#define K1_DBG_NO_EXACT 0		/* measurement only: 1 drops the exact path (wrong bins on near-ties) */
 #endif
 static __device__ __forceinline__ float bin_fast(float re, float im, const BinConst &k, float *l2_out, uint32_t *amb_bits)
 {
@@ -475,12 +549,6 @@ void k1_fft_bin(const K1Params p)
 				else
 					pack[m] ^= __float_as_uint(r);
 			}
-#ifndef K1_THR_LDS
-#define K1_THR_LDS 1			/* 0: the thresholds read from memory (A/B builds) */
-#endif
-#ifndef K1_DBG_NO_EXACT
-#define K1_DBG_NO_EXACT 0		/* measurement only: 1 drops the exact path (wrong bins on near-ties) */
-#endif
 			if (!K1_DBG_NO_EXACT && amb > __float_as_uint(bk.amb)) {
 				/* rare (a few % of spectra have one such sample): find the samples, decide them
 				 * against the exact thresholds, patch their bin byte and log-power */
@@ -805,7 +873,7 @@ void k1v2_fft_bin(const K1Params p)
 					if (!(a <= bk.amb)) {
 						const int guess = (int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
 						float nl2;
-						const uint32_t nbn = bin_exact(x[q].x, x[q].y, l2[q], guess, bk.thr, bk.nb, &nl2);
+						const uint32_t nbn = bin_exact(x[q].x, x[q].y, l2[q], guess, ThrScalar{ bk.thr }, bk.nb, &nl2);
 						pack[q] = (pack[q] & ~(0xffu << (8 * u))) | (nbn << (8 * u));
 						l2[q] = nl2;
 					}
@@ -969,7 +1037,7 @@ void k1big_fft_bin(const K1Params p)
 					const float a = __builtin_fmaf(__builtin_fabsf(l2[q]), bk.kappa, __builtin_fabsf(v - rr));
 					if (!(a <= bk.amb)) {
 						float nl2;
-						bn[q] = bin_exact(x[q].x, x[q].y, l2[q], (int)bn[q], bk.thr, bk.nb, &nl2);
+						bn[q] = bin_exact(x[q].x, x[q].y, l2[q], (int)bn[q], ThrScalar{ bk.thr }, bk.nb, &nl2);
 						l2[q] = nl2;
 					}
 				}
@@ -1090,17 +1158,32 @@ void k1w_fft_bin(const K1Params p)
 		const bool _row = ((tp) >= p.wf_first); \
 		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + th; \
 		uint16_t *_bd = bins16 + ((size_t)((tp) >> 1) * N + th) * 2 + ((tp) & 1); \
+		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
 		_Pragma("unroll") \
 		for (int m = (M0); m < (M1); m++) { \
-			float l2v; uint32_t ab; \
-			const float rr = bin_fast(xo[m].x, xo[m].y, bk, &l2v, &ab); \
-			uint32_t bn = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top); \
-			if (ab > __float_as_uint(bk.amb)) {		/* rare: decided against the exact thresholds */ \
-				float nl2; \
-				bn = bin_exact(xo[m].x, xo[m].y, l2v, (int)bn, bk.thr, bk.nb, &nl2); \
-				l2v = nl2; \
+			uint32_t ab; \
+			const float rr = bin_fast(xo[m].x, xo[m].y, bk, &_l2[m - (M0)], &ab); \
+			_amb = _amb > ab ? _amb : ab;		/* v_max_u32: NaN / inf order above every finite measure */ \
+			_bn[m - (M0)] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top); \
+		} \
+		/* ONE branch per piece (a compare + exec save + branch per sample cost 9 % of this kernel): rare -- find the samples again \
+		 * and decide them against the exact thresholds */ \
+		if (!K1_DBG_NO_EXACT && _amb > __float_as_uint(bk.amb)) { \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) { \
+				const float v = __builtin_fmaf(bk.A, _l2[m - (M0)], bk.C); \
+				const float a = __builtin_fmaf(__builtin_fabsf(_l2[m - (M0)]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v))); \
+				if (!(a <= bk.amb)) { \
+					float nl2; \
+					_bn[m - (M0)] = bin_exact(xo[m].x, xo[m].y, _l2[m - (M0)], (int)_bn[m - (M0)], ThrScalar{ bk.thr }, bk.nb, &nl2); \
+					_l2[m - (M0)] = nl2; \
+				} \
 			} \
-			_bd[2 * TH * m] = (uint16_t)bn; \
+		} \
+		_Pragma("unroll") \
+		for (int m = (M0); m < (M1); m++) { \
+			const float l2v = _l2[m - (M0)]; \
+			_bd[2 * TH * m] = (uint16_t)_bn[m - (M0)]; \
 			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
 			vmax[m] = max_f32(vmax[m], l2v); \
 			if (_row) _wf[TH * m] = l2v * F_HALF_LOG10_2; \
@@ -1695,25 +1778,46 @@ void k1h_fused(const K1Params p)
 		const bool store_row = (t >= p.wf_first) && !(p.dbg_k1h & 4);
 		const uint32_t wf_so = (uint32_t)((p.wf_pos0 + t) & p.wf_mask) * (uint32_t)(N * 4);
 		const int sh8 = 8 * (u & 3);
+		/* four samples at a time: fast path, ONE branch for the four (rare: some sample is not provably exact -- find it again and
+		 * decide it against the exact thresholds), then the updates and stores */
 #pragma unroll
-		for (int c = 0; c < 16; c++) {
-			const v2f x = r[R16_PERM(c)];
-			float l2v; uint32_t ab;
-			const float rr = bin_fast(x.x, x.y, bk, &l2v, &ab);
-			uint32_t bn = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
-			if (ab > __float_as_uint(bk.amb) && !(p.dbg_k1h & 16)) {		/* rare: decided against the exact thresholds */
-				float nl2;
-				bn = bin_exact(x.x, x.y, l2v, (int)bn, thr_l, bk.nb, &nl2);
-				l2v = nl2;
+		for (int g = 0; g < 4; g++) {
+			float l2g[4]; uint32_t bng[4]; uint32_t amb = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const v2f x = r[R16_PERM(4 * g + k)];
+				uint32_t ab;
+				const float rr = bin_fast(x.x, x.y, bk, &l2g[k], &ab);
+				amb = amb > ab ? amb : ab;		/* v_max_u32: NaN / inf order above every finite measure */
+				bng[k] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
 			}
-			plo[c] |= (bn & 0xffu) << sh8;
-			phi[c] |= (bn >> 8) << u;
-			live[c] = __builtin_fmaf(live[c], p.w, l2v);
-			vmax[c] = max_f32(vmax[c], l2v);
-			/* rows and bin indices are streamed out non-temporally: plain stores allocate in the XCD's L2 and push the cluster's
-			 * intermediate out of it */
-			if (store_row)
-				__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, kAuxNT);
+			if (amb > __float_as_uint(bk.amb) && !(p.dbg_k1h & 16)) {
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const v2f x = r[R16_PERM(4 * g + k)];
+					const float v = __builtin_fmaf(bk.A, l2g[k], bk.C);
+					const float a = __builtin_fmaf(__builtin_fabsf(l2g[k]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v)));
+					if (!(a <= bk.amb)) {
+						float nl2;
+						bng[k] = bin_exact(x.x, x.y, l2g[k], (int)bng[k], thr_l, bk.nb, &nl2);
+						l2g[k] = nl2;
+					}
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const int c = 4 * g + k;
+				const uint32_t bn = bng[k];
+				const float l2v = l2g[k];
+				plo[c] |= (bn & 0xffu) << sh8;
+				phi[c] |= (bn >> 8) << u;
+				live[c] = __builtin_fmaf(live[c], p.w, l2v);
+				vmax[c] = max_f32(vmax[c], l2v);
+				/* rows and bin indices are streamed out non-temporally: plain stores allocate in the XCD's L2 and push the cluster's
+				 * intermediate out of it */
+				if (store_row)
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, kAuxNT);
+			}
 		}
 		if ((u & 3) == 3 && !(p.dbg_k1h & 4)) {
 			const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(bins_lo + (size_t)(t >> 2) * N);
@@ -1865,7 +1969,7 @@ void k_bin_hook(const float2 *__restrict__ fft, uint8_t *__restrict__ bin, float
 		 * (<= 256 bins) or clamp + integer convert (16-bit indices) */
 		uint32_t b = p.bins16 ? (uint32_t)(int)__builtin_amdgcn_fmed3f(r, 0.0f, top) : (pack_bin(r, top, 0, 0) & 0xff);
 		if (ab > __float_as_uint(bk.amb) || force_exact)
-			b = bin_exact(v.x, v.y, l2, (int)__builtin_amdgcn_fmed3f(r, 0.0f, top), bk.thr, bk.nb, &l2);
+			b = bin_exact(v.x, v.y, l2, (int)__builtin_amdgcn_fmed3f(r, 0.0f, top), ThrScalar{ bk.thr }, bk.nb, &l2);
 		if (p.bins16)
 			reinterpret_cast<uint16_t *>(bin)[i] = (uint16_t)b;
 		else
