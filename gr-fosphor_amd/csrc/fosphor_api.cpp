@@ -118,7 +118,8 @@ struct fosphor
 	uint32_t *d_rowmask;			/* K2 -> K3: one bit per (batch, slab, bin row) "this row has counts and is stored"; 2 sets */
 	int       mask_words;			/* ceil(n_bins / 32) */
 	uint8_t  *d_hot;			/* [N/64][n_bins]: some cell of the row is above the fast-exit level (K3 maintains it) */
-	uint32_t *d_rowlist;			/* [1 + rows]: the live rows of a merge (sparse form) */
+	uint32_t *d_rowlist;			/* [2 + rows]: the live rows of a merge (sparse form) between two counts used alternately */
+	int       rowlist_flip;
 	int       hot_valid;			/* 0 after anything but the 16-bit K3 wrote the histogram */
 	uint16_t *d_slab16;			/* per-chunk packed 16-bit count slabs of batches longer than 1024 spectra / of a shard */
 	int       slab_chunks;			/* capacity of d_slab16 in 1024-spectrum chunks */
@@ -520,7 +521,9 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_rowmask, sizeof(uint32_t) * 2 * (size_t)self->max_batches * (self->n / 64) * self->mask_words), "alloc row masks");
 	HIP_TRY(hipMalloc((void **)&self->d_hot, (size_t)(self->n / 64) * self->n_bins), "alloc row flags");
 	HIP_TRY(hipMemset(self->d_hot, 1, (size_t)(self->n / 64) * self->n_bins), "set row flags");
-	HIP_TRY(hipMalloc((void **)&self->d_rowlist, sizeof(uint32_t) * (1 + (size_t)(self->n / 64) * self->n_bins)), "alloc row list");
+	HIP_TRY(hipMalloc((void **)&self->d_rowlist, sizeof(uint32_t) * (2 + (size_t)(self->n / 64) * self->n_bins)), "alloc row list");
+	HIP_TRY(hipMemset(self->d_rowlist, 0, sizeof(uint32_t) * (2 + (size_t)(self->n / 64) * self->n_bins)), "clear row list");
+	self->rowlist_flip = 0;
 	self->hot_valid = 0;
 	if (self->max_spectra > 1024) {
 		/* one slab per 1024-spectrum chunk of the largest launch: a whole shard (accumulate) or a sub-launch */
@@ -942,6 +945,8 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 			self->export_mask = k3.rowmask + (n_batches - 1);
 			k3.hot = self->d_hot;
 			k3.rowlist = self->d_rowlist;
+			k3.rowlist_cnt = self->rowlist_flip ? 1 + self->n_bins * (self->n / 64) : 0;
+			self->rowlist_flip ^= 1;
 			k3.hot_all = !self->hot_valid;
 			self->hot_valid = 1;
 		} else {

@@ -130,7 +130,8 @@ struct K3Params {
 					 * (display.cl:237)", maintained here; a row that is not hot and has no count in any batch of
 					 * the launch is skipped without reading its cells */
 	int   hot_all;			/* the flags are stale (another kernel wrote the histogram): visit every row, rewrite them */
-	uint32_t *rowlist;		/* sparse form: [1 + rows] count, then the live rows (k3_scan writes, k3_merge reads) */
+	uint32_t *rowlist;		/* sparse form: [2 + rows] count, the live rows, second count (k3_scan writes, k3_merge reads) */
+	int   rowlist_cnt;		/* ... which of the two counts this launch uses: 0, or 1 + rows (alternating) */
 };
 
 hipError_t launch_k1(const K1Params &p, hipStream_t s);
