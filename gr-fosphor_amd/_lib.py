@@ -111,6 +111,7 @@ SIGNATURES = {
     "fosphor_amd_wait_input": (C.c_int, [C.c_void_p]),
     "fosphor_amd_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
+    "fosphor_amd_upload_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_version": (C.c_char_p, []),
     # include/fosphor_amd_axis.h
     "fosphor_amd_freq_axis_build": (None, [C.c_void_p, C.c_double, C.c_double, C.c_int]),
@@ -123,6 +124,9 @@ SIGNATURES = {
                                        C.c_int, C.c_void_p]),
     # include/fosphor_amd_sink.h
     "fosphor_amd_process_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fosphor_amd_upload_pinned": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "fosphor_amd_process_uploaded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "fosphor_amd_pending_uploads": (C.c_int, [C.c_void_p]),
     "fosphor_amd_wait_upload": (C.c_int, [C.c_void_p]),
     "fosphor_amd_fifo_new": (C.c_void_p, [C.c_int, C.c_int]),
     "fosphor_amd_fifo_free": (None, [C.c_void_p]),

@@ -143,6 +143,12 @@ struct fosphor
 	float2   *d_stage[2];
 	hipEvent_t stage_free[2];
 	hipEvent_t upload_done;			/* H2D of the last fosphor_amd_process_pinned */
+	hipStream_t copy_stream;		/* ... queued here, so that the upload of one batch runs beside the kernels of the batch before
+						 * (created by the first fosphor_amd_process_pinned) */
+	hipEvent_t upload_slot[2];		/* upload into d_stage[k] done: the instance's stream waits for it before the FFT kernel */
+	int       stage_used[2];
+	size_t    d_stage_cap[2];		/* samples d_stage[k] holds */
+	int       pend_slot[2], pend_len[2], pend_head, pend_n;	/* uploads queued by fosphor_amd_upload_pinned, kernels not yet */
 	int       stage_idx;
 	double   *h_thr;			/* pinned, n_bins+1 */
 	float    *h_win;			/* pinned, N */
@@ -298,6 +304,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_k1_done[i]) (void)hipEventDestroy(self->ev_k1_done[i]);
 		if (self->ev_set_free[i]) (void)hipEventDestroy(self->ev_set_free[i]);
 	}
+	if (self->copy_stream) { (void)hipStreamSynchronize(self->copy_stream); (void)hipStreamDestroy(self->copy_stream); }
 	if (self->stream2) { (void)hipStreamSynchronize(self->stream2); (void)hipStreamDestroy(self->stream2); }
 	if (self->stream3) { (void)hipStreamSynchronize(self->stream3); (void)hipStreamDestroy(self->stream3); }
 	for (int i = 0; i < 2; i++) {
@@ -323,6 +330,8 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->stage_free[i]) (void)hipEventDestroy(self->stage_free[i]);
 	}
 	if (self->upload_done) (void)hipEventDestroy(self->upload_done);
+	for (int i = 0; i < 2; i++)
+		if (self->upload_slot[i]) (void)hipEventDestroy(self->upload_slot[i]);
 	if (self->h_thr) (void)hipHostFree(self->h_thr);
 	if (self->h_win) (void)hipHostFree(self->h_win);
 	for (hipEvent_t e : self->ev_pool) (void)hipEventDestroy(e);
@@ -1202,8 +1211,10 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	/* (each piece behind its own check: fosphor_amd_process_pinned shares d_stage / stage_free) */
 	if (!self->h_stage[k])
 		HIP_TRY(hipHostMalloc((void **)&self->h_stage[k], sample_bytes * self->stage_samples, hipHostMallocDefault), "alloc pinned staging");
-	if (!self->d_stage[k])
+	if (!self->d_stage[k]) {
 		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
+		self->d_stage_cap[k] = self->stage_samples;
+	}
 	if (!self->stage_free[k])
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	else
@@ -1223,29 +1234,98 @@ error:
 	return -EIO;
 }
 
-extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len)
+/* The upload of fosphor_amd_process_pinned and its kernels as two calls: a host that queues the NEXT upload before it waits for the
+ * kernels of this one (the streaming sink: its per-frame synchronisation point drains the kernel streams, not the upload stream)
+ * keeps the link busy across frames.  At most two uploads can be pending (two staging buffers): -EBUSY beyond. */
+extern "C" int fosphor_amd_upload_pinned(struct fosphor *self, const void *samples, int len)
 {
-	int k, rv;
+	int k;
 	const size_t sample_bytes = self->iq_half ? 4 : sizeof(float2);
 
-	if (len <= 0 || (len & ((16 * self->n) - 1)) || (long long)len > (long long)self->n * 1024 || len / self->n > self->max_spectra)
-		return -EINVAL;		/* cl.c:882-886 */
+	/* cl.c:882-886 for one batch; beyond it a whole number of 1024-spectrum batches in one call (applied one after the other like so
+	 * many calls, one upload and one set of launches: what the host spends per call -- ~250 us -- is then spent per 64 MiB, not per 8) */
+	const long long one = (long long)self->n * 1024;
+	if (len <= 0 || (len & ((16 * self->n) - 1)) || len / self->n > self->max_spectra || ((long long)len > one && (long long)len % one))
+		return -EINVAL;
+	if (((long long)len > one ? (int)((long long)len / one) : 1) > self->max_batches)
+		return -EINVAL;
+	if (self->pend_n == 2)
+		return -EBUSY;
 
 	k = self->stage_idx;
-	if (!self->d_stage[k])
-		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * self->stage_samples), "alloc device staging");
+	if (self->d_stage[k] && self->d_stage_cap[k] < (size_t)len) {		/* grown on demand (behind everything that reads the old one) */
+		HIP_TRY(hipDeviceSynchronize(), "drain before regrowing the staging buffer");
+		(void)hipFree(self->d_stage[k]);
+		self->d_stage[k] = NULL;
+	}
+	if (!self->d_stage[k]) {
+		const size_t cap = (size_t)len > self->stage_samples ? (size_t)len : self->stage_samples;
+		HIP_TRY(hipMalloc((void **)&self->d_stage[k], sample_bytes * cap), "alloc device staging");
+		self->d_stage_cap[k] = cap;
+	}
 	if (!self->stage_free[k])
 		HIP_TRY(hipEventCreateWithFlags(&self->stage_free[k], hipEventDisableTiming), "create staging event");
 	if (!self->upload_done)
 		HIP_TRY(hipEventCreateWithFlags(&self->upload_done, hipEventDisableTiming), "create upload event");
-	/* d_stage[k] was last read by a K1 queued earlier on the same stream: ordered by the stream */
-	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sample_bytes * (size_t)len, hipMemcpyHostToDevice, self->stream), "H2D samples (pinned)");
-	HIP_TRY(hipEventRecord(self->upload_done, self->stream), "record upload");
-	rv = run(self, self->d_stage[k], 1, len / self->n);
+	if (!self->copy_stream)
+		HIP_TRY(hipStreamCreateWithFlags(&self->copy_stream, hipStreamNonBlocking), "create upload stream");
+	if (!self->upload_slot[k])
+		HIP_TRY(hipEventCreateWithFlags(&self->upload_slot[k], hipEventDisableTiming), "create upload event");
+	/* The upload runs on its own stream, beside the kernels of the batch before it (on one stream a batch cost its 150 us of DMA PLUS
+	 * its kernels: 3.9 GSamples/s where the link does 7).  d_stage[k] was last read by the FFT kernel of the call before the last:
+	 * the copy waits for the event recorded behind that call; the instance's stream waits for the copy. */
+	if (self->stage_used[k])
+		HIP_TRY(hipStreamWaitEvent(self->copy_stream, self->stage_free[k], 0), "upload waits for the staging slot");
+	HIP_TRY(hipMemcpyAsync(self->d_stage[k], samples, sample_bytes * (size_t)len, hipMemcpyHostToDevice, self->copy_stream), "H2D samples (pinned)");
+	HIP_TRY(hipEventRecord(self->upload_slot[k], self->copy_stream), "record upload");
+	HIP_TRY(hipEventRecord(self->upload_done, self->copy_stream), "record upload");
+	self->pend_slot[(self->pend_head + self->pend_n) & 1] = k;
+	self->pend_len[(self->pend_head + self->pend_n) & 1] = len;
+	self->pend_n++;
 	self->stage_idx ^= 1;
+	return 0;
+error:
+	return -EIO;
+}
+
+extern "C" int fosphor_amd_pending_uploads(struct fosphor *self)
+{
+	return self ? self->pend_n : 0;
+}
+
+/* The kernels for the oldest pending upload; *len_out = its samples.  -EINVAL when nothing is pending. */
+extern "C" int fosphor_amd_process_uploaded(struct fosphor *self, int *len_out)
+{
+	if (!self || !self->pend_n)
+		return -EINVAL;
+	const int k = self->pend_slot[self->pend_head], len = self->pend_len[self->pend_head];
+	const long long one = (long long)self->n * 1024;
+	const int n_batches = (long long)len > one ? (int)((long long)len / one) : 1;
+	int rv;
+	self->pend_head ^= 1;
+	self->pend_n--;
+	if (len_out)
+		*len_out = len;
+	HIP_TRY(hipStreamWaitEvent(self->stream, self->upload_slot[k], 0), "kernels wait for the upload");
+	rv = run(self, self->d_stage[k], n_batches, len / self->n / n_batches);
+	if (hipEventRecord(self->stage_free[k], self->stream) != hipSuccess && !rv)
+		rv = -EIO;
+	self->stage_used[k] = 1;
 	return rv;
 error:
 	return -EIO;
+}
+
+extern "C" int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len)
+{
+	int rv;
+	/* (uploads queued by fosphor_amd_upload_pinned and not yet processed come first: the stream is applied in order) */
+	while (self->pend_n)
+		if ((rv = fosphor_amd_process_uploaded(self, NULL)) != 0)
+			return rv;
+	if ((rv = fosphor_amd_upload_pinned(self, samples, len)) != 0)
+		return rv;
+	return fosphor_amd_process_uploaded(self, NULL);
 }
 
 extern "C" int fosphor_amd_wait_upload(struct fosphor *self)
@@ -1873,6 +1953,11 @@ extern "C" int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samp
 extern "C" void *fosphor_amd_stream(struct fosphor *self)
 {
 	return self ? (void *)self->stream : NULL;
+}
+
+extern "C" void *fosphor_amd_upload_stream(struct fosphor *self)
+{
+	return self ? (void *)(self->copy_stream ? self->copy_stream : self->stream) : NULL;
 }
 
 /* private accessor for fosphor_render.cpp (keeps struct fosphor opaque there) */

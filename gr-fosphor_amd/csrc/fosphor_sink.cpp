@@ -369,7 +369,23 @@ bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, dou
 void sink_runtime::worker()						/* :77-122 */
 {
 	{
-		struct fosphor *f = fosphor_init();
+		/* the reference's instance (fosphor_init(): one 1024-spectrum batch per call); with a FIFO that can hold several batches,
+		 * room for eight per call (render() below) */
+		struct fosphor *f;
+		int per_call = d_fifo->capacity() / (2 * 1024 * 1024);		/* half the FIFO per call at most: the producer keeps the other half */
+		if (per_call > 8) per_call = 8;
+		if (per_call >= 2) {
+			struct fosphor_amd_config cfg;
+			memset(&cfg, 0, sizeof(cfg));
+			cfg.max_spectra = per_call * 1024;
+			f = fosphor_amd_init(&cfg);
+			d_batches_per_call = f ? per_call : 1;
+			if (!f)
+				f = fosphor_init();
+		} else {
+			f = fosphor_init();
+			d_batches_per_call = 1;
+		}
 		std::lock_guard<std::mutex> lk(d_render_mutex);
 		d_fosphor = f;
 	}
@@ -380,6 +396,11 @@ void sink_runtime::worker()						/* :77-122 */
 	settings_apply(~(uint32_t)0);					/* :106-109 (+ the pane layout: no window system sends a first reshape here) */
 	while (d_active || (d_draining && d_fifo->used() - d_inflight_samples >= 16 * 1024))
 		render();
+	while (fosphor_amd_pending_uploads(d_fosphor) > 0) {			/* the kernels of the last uploads */
+		int plen = 0;
+		if (fosphor_amd_process_uploaded(d_fosphor, &plen) == 0)
+			d_samples += (uint64_t)plen;
+	}
 	(void)fosphor_amd_finish(d_fosphor);
 	retire_uploads(true);
 	{
@@ -397,12 +418,27 @@ void sink_runtime::render()						/* :130-201 */
 	settings_apply(settings_get_and_reset_changed());
 
 	retire_uploads(false);
+	/* the kernels of what the previous pass uploaded (pinned FIFO: a pass queues uploads, the next pass their kernels -- the
+	 * synchronisation point at the end of a pass then waits for kernels only and the link works on across it) */
+	while (fosphor_amd_pending_uploads(d_fosphor) > 0) {
+		int plen = 0;
+		if (fosphor_amd_process_uploaded(d_fosphor, &plen) == 0)
+			d_samples += (uint64_t)plen;
+		queued++;
+	}
 	for (i = 0; i < max_iter; i++) {
 		/* the next region starts behind the ones still in flight (they are not discarded yet) */
 		int len = d_fifo->peek_max_size_at(d_inflight_samples);
 		len &= ~((batch_mult * fft_len) - 1);			/* :156 */
-		if (len > (batch_max * fft_len))
-			len = batch_max * fft_len;			/* :157-158 */
+		if (len > (batch_max * fft_len)) {
+			/* :157-158 caps a call at one batch.  Here a call may carry up to d_batches_per_call WHOLE batches -- they are applied one
+			 * after the other, exactly like that many calls -- because what bounds this loop is the host's time per call (one
+			 * upload, a dozen launches and events: ~250 us, against 150 us of DMA per batch) */
+			const int nb = len / (batch_max * fft_len);
+			len = (nb < d_batches_per_call ? nb : d_batches_per_call) * (batch_max * fft_len);
+			if (!d_fifo->pinned())
+				len = batch_max * fft_len;
+		}
 		if (!len)
 			break;
 		if (d_inflight_n == kMaxInflight)
@@ -415,21 +451,23 @@ void sink_runtime::render()						/* :130-201 */
 			if (d_fifo->pinned()) {
 				/* DMA straight from the ring; the region goes back to the producer once the event behind
 				 * its copy has completed -- nothing waits here, the next region's copy queues behind it */
-				rv = fosphor_amd_process_pinned(d_fosphor, data, len);
+				rv = fosphor_amd_upload_pinned(d_fosphor, data, len);
+				if (rv == -EBUSY)
+					break;				/* both staging buffers hold uploads: their kernels come first (next pass) */
 				if (!d_events[slot]) {
 					hipEvent_t e;
 					if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
 						d_events[slot] = e;
 				}
-				if (d_events[slot] && hipEventRecord((hipEvent_t)d_events[slot], (hipStream_t)fosphor_amd_stream(d_fosphor)) == hipSuccess)
+				if (d_events[slot] && hipEventRecord((hipEvent_t)d_events[slot], (hipStream_t)fosphor_amd_upload_stream(d_fosphor)) == hipSuccess)
 					ev = d_events[slot];
 				else
 					(void)fosphor_amd_wait_upload(d_fosphor);
 			} else {
 				rv = fosphor_process(d_fosphor, data, len);	/* copies before it returns */
+				if (rv == 0)
+					d_samples += (uint64_t)len;
 			}
-			if (rv == 0)
-				d_samples += (uint64_t)len;
 		}
 		d_inflight[slot].event = ev;
 		d_inflight[slot].len = len;
@@ -444,7 +482,7 @@ void sink_runtime::render()						/* :130-201 */
 		if (d_zoom_applied)
 			fosphor_draw(d_fosphor, d_render_zoom);		/* :189-190 */
 		d_frames++;
-		retire_uploads(true);
+		retire_uploads(false);		/* (the uploads queued in this pass run on: their regions go back as their events complete) */
 	} else {
 		std::this_thread::sleep_for(std::chrono::milliseconds(10));	/* :197-200 */
 		retire_uploads(false);

@@ -243,6 +243,10 @@ int fosphor_amd_wait_input(struct fosphor *self);
  * pipeline is on).  The all-reduce between accumulate and merge must be ordered on the latter. */
 void *fosphor_amd_stream(struct fosphor *self);
 void *fosphor_amd_stream2(struct fosphor *self);
+/* hipStream_t the uploads of fosphor_amd_process_pinned are queued on (the instance's own stream until the first such
+ * call): an event recorded here behind a call completes when that call's samples have left the caller's buffer --
+ * replaces the reference's blocking upload, lib/fosphor/cl.c:903-910. */
+void *fosphor_amd_upload_stream(struct fosphor *self);
 
 /* Library identification: "fosphor_amd <version> gfx950". */
 const char *fosphor_amd_version(void);

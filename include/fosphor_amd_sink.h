@@ -50,6 +50,7 @@ class fifo
 	fifo &operator=(const fifo &) = delete;
 
 	int free() const { return capacity_ - 1 - used(); }
+	int capacity() const { return capacity_; }
 	int used() const { return (int)(committed_.load(std::memory_order_seq_cst) - discarded_.load(std::memory_order_seq_cst)); }
 
 	int write_max_size() const { return capacity_ - (int)(committed_.load(std::memory_order_relaxed) & mask_); }
@@ -171,6 +172,7 @@ class sink_runtime
 	enum { kMaxInflight = 32 };
 	struct { void *event; int len; } d_inflight[kMaxInflight];
 	int d_inflight_head, d_inflight_n, d_inflight_samples;
+	int d_batches_per_call;		/* whole 1024-spectrum batches one fosphor_amd_process_pinned call may carry */
 	void *d_events[kMaxInflight];
 
 	/* Helper threads for large copies in work().  The link behind the FIFO carries ~63 GB/s (PCIe Gen5 x16), one core
@@ -208,6 +210,14 @@ extern "C" {
  * returns.  Same len rules and return codes as fosphor_process (cl.c:882-886). */
 int fosphor_amd_process_pinned(struct fosphor *self, const void *samples, int len);
 int fosphor_amd_wait_upload(struct fosphor *self);
+/* The same in two steps, so that the next upload can be queued before the kernels of this one are waited for (the sink's frame
+ * loop): fosphor_amd_upload_pinned queues the H2D alone (len as above, or a whole number of 1024-spectrum batches up to the
+ * instance's max_spectra: they are applied one after the other like so many calls; -EBUSY while two uploads are pending),
+ * fosphor_amd_process_uploaded queues the kernels of the oldest pending upload (*len_out = its samples; -EINVAL if none).
+ * fosphor_amd_process_pinned = both. */
+int fosphor_amd_upload_pinned(struct fosphor *self, const void *samples, int len);
+int fosphor_amd_process_uploaded(struct fosphor *self, int *len_out);
+int fosphor_amd_pending_uploads(struct fosphor *self);
 
 typedef struct fosphor_amd_fifo fosphor_amd_fifo;
 fosphor_amd_fifo *fosphor_amd_fifo_new(int length, int pinned);
