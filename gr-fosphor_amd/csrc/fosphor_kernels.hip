@@ -1635,6 +1635,9 @@ void k1h_fused(const K1Params p)
 			ra[j] = v2f{ xv.x * wina[j], xv.y * wina[j] };		/* window, fft.cl:415-417 */
 		}
 		dft16(ra, s12, c16);
+	};
+	/* ... and the 16 x 16 transpose inside the wave that follows it */
+	auto stage_a1x = [&]() {
 #pragma unroll
 		for (int jj = 0; jj < 16; jj++)
 			xa[ea_w + 17 * jj] = ra[R16_PERM(jj)];
@@ -1686,6 +1689,7 @@ void k1h_fused(const K1Params p)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	wg_barrier_lds();
 	stage_a1(t0, 0);
+	stage_a1x();
 	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
 	if (2 < p.tile)
 		fetch_iq(t0 + 2, 0);
@@ -1721,7 +1725,8 @@ void k1h_fused(const K1Params p)
 		wg_barrier_lds();
 		if (tid == 0)
 			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
+		if (more)
+			stage_a1x();					/* (while the arrivals travel) */
 
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
 			uint32_t spins = 0;
