@@ -1725,8 +1725,12 @@ void k1h_fused(const K1Params p)
 		wg_barrier_lds();
 		if (tid == 0)
 			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (more)
+		if (more) {
 			stage_a1x();					/* (while the arrivals travel) */
+#pragma unroll
+			for (int j = 1; j < 16; j++)
+				ra[j] = c_mul(ra[j], twa_t[ia * 15 + j - 1]);
+		}
 
 		if (tid == 0 && !(p.dbg_k1h & 1)) {
 			uint32_t spins = 0;
@@ -1751,7 +1755,7 @@ void k1h_fused(const K1Params p)
 				r[j] = ra[j];
 		}
 		if (more)
-			stage_a2();					/* (while the loads travel) */
+			dft16(ra, s12, c16);				/* (while the loads travel) */
 #pragma unroll
 		for (int j = 1; j < 16; j++)					/* pass 3, p = 256, k = kk */
 			r[j] = c_mul(r[j], tw3_t[kkl * 15 + j - 1]);
