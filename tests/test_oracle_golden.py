@@ -95,6 +95,22 @@ def test_fft1024_is_a_dft(oracle_built):
     assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 5e-7
 
 
+@pytest.mark.parametrize("log2n", [13, 16])
+def test_long_fft_plans_are_dfts(oracle_built, log2n):
+    """No reference behaviour exists beyond N = 1024: the plans are the oracle's (8192: the generalisation of fft.cl:397-466,
+    radix 8.8.8.8.2; 65536: this build's radix-16 plan, o_dft16 / o_pass_radix16).  Whatever the plan, it must BE a forward,
+    unnormalised, natural-order DFT -- as accurate against numpy's fp64 FFT as the reference's own 1024-point kernel is."""
+    n = 1 << log2n
+    rng = np.random.default_rng(1300 + log2n)
+    x = (rng.standard_normal((2 * n, 2)) * 0.5).astype(np.float32)
+    win = (0.5 + 0.5 * rng.random(n)).astype(np.float32)
+    y = Oracle.fft(x, win, fft_len_log=log2n)
+    xr = x.reshape(2, n, 2).astype(np.float64)
+    ref = np.fft.fft((xr[..., 0] + 1j * xr[..., 1]) * win.astype(np.float64), axis=-1)
+    got = y.reshape(2, n, 2)[..., 0].astype(np.float64) + 1j * y.reshape(2, n, 2)[..., 1]
+    assert np.max(np.abs(got - ref)) / np.max(np.abs(ref)) < 1e-6
+
+
 def test_edge_semantics_in_fixtures():
     """Properties the reference fixtures exhibit (documented behaviour the HIP path must keep)."""
     z = np.load(os.path.join(GOLD, "c3_zero_b16.npz"))
