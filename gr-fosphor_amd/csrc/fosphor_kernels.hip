@@ -1420,6 +1420,12 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *b
 	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);	/* raw buffer, 32-bit data format */
 }
 constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of the buffer intrinsics: nt, sc1 */
+#ifndef K1H_OUT_AUX
+#define K1H_OUT_AUX 2				/* cache policy of the 65536-point kernel's row / index stores (A/B builds) */
+#endif
+#ifndef K1H_IQ_MOD
+#define K1H_IQ_MOD "nt"				/* ... and of its LDS-DMA of the IQ */
+#endif
 template <int AUX>
 static __device__ __forceinline__ void bst_v2f(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
 {
@@ -1557,9 +1563,11 @@ void k1h_fused(const K1Params p)
 #pragma unroll
 	for (int i = 0; i < 4; i++)
 		c16[i] = twg[p.tw_off[0] + i];
-	float wina[16];							/* the 16 window taps of this thread's pass-1 item */
+	float wina[HALF ? 16 : 1];					/* the 16 window taps of this thread's pass-1 item (fp32 IQ, not a BASELINE
+									 * configuration at this length: read where they are used -- its 32 staging
+									 * registers leave no room for them) */
 #pragma unroll
-	for (int j = 0; j < 16; j++)
+	for (int j = 0; j < (HALF ? 16 : 1); j++)
 		wina[j] = p.win[qa + 256 * (ia + 16 * j)];
 	v2f tw4[15];
 #pragma unroll
@@ -1611,7 +1619,7 @@ void k1h_fused(const K1Params p)
 			const uint32_t *sk = src + 2048 * g;						/* 8 rows of 1 KiB */
 			const uint32_t la = inb_lds + 4u * (unsigned)(buf * kInLen + 256 * g);
 			uint32_t keep;
-			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 " K1H_IQ_MOD "\n\ts_mov_b32 m0, %0"
 			             : "=&s"(keep) : "v"(iq_vo), "s"(sk), "s"(la) : "memory");
 		}
 	};
@@ -1632,7 +1640,8 @@ void k1h_fused(const K1Params p)
 			} else {
 				xv = bld_v2f<kAuxNT>(rs_f, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
 			}
-			ra[j] = v2f{ xv.x * wina[j], xv.y * wina[j] };		/* window, fft.cl:415-417 */
+			const float wj = HALF ? wina[HALF ? j : 0] : p.win[qa + 256 * (ia + 16 * j)];
+			ra[j] = v2f{ xv.x * wj, xv.y * wj };			/* window, fft.cl:415-417 */
 		}
 		dft16(ra, s12, c16);
 	};
@@ -1838,14 +1847,14 @@ void k1h_fused(const K1Params p)
 				/* rows and bin indices are streamed out non-temporally: plain stores allocate in the XCD's L2 and push the cluster's
 				 * intermediate out of it */
 				if (store_row)
-					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, kAuxNT);
+					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, K1H_OUT_AUX);
 			}
 		}
 		if ((u & 3) == 3 && !(p.dbg_k1h & 4)) {
 			const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(bins_lo + (size_t)(t >> 2) * N);
 #pragma unroll
 			for (int c = 0; c < 16; c++) {
-				__builtin_amdgcn_raw_buffer_store_b32(plo[c], rs_lo, 4u * ucol0, 16384u * c, kAuxNT);
+				__builtin_amdgcn_raw_buffer_store_b32(plo[c], rs_lo, 4u * ucol0, 16384u * c, K1H_OUT_AUX);
 				plo[c] = 0;
 			}
 		}
@@ -1854,7 +1863,7 @@ void k1h_fused(const K1Params p)
 		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
 #pragma unroll
 		for (int c = 0; c < 16; c++)
-			__builtin_amdgcn_raw_buffer_store_b32(phi[c], rs_hi, 4u * ucol0, 16384u * c, kAuxNT);
+			__builtin_amdgcn_raw_buffer_store_b32(phi[c], rs_hi, 4u * ucol0, 16384u * c, K1H_OUT_AUX);
 	}
 #pragma unroll
 	for (int c = 0; c < 16; c++)

@@ -1123,6 +1123,45 @@ def test_sink_zero_copy_feed(amd, torch_cuda, oracle_built):
     L.fosphor_amd_sink_free(s)
 
 
+def test_upload_and_kernels_in_two_steps(amd, torch_cuda, oracle_built):
+    """fosphor_amd_upload_pinned / fosphor_amd_process_uploaded (what the sink's frame loop calls): two uploads may be pending, a
+    third is refused with -EBUSY, the kernels are queued oldest first, and a call that carries several whole batches is applied like
+    so many calls.  State against the oracle after every step."""
+    import ctypes as C
+    import errno
+    torch = torch_cuda
+    L = amd.load()
+    f = amd.Fosphor(max_spectra=3072)
+    o = Oracle()
+    x = add_tone(gaussian_iq(5 * 1024 * 1024 + 48 * 1024, 97), 0.2, 0.37)
+    pin = torch.from_numpy(x).pin_memory()
+    base = pin.data_ptr()
+    a, b = 48 * 1024, 1024 * 1024
+    assert L.fosphor_amd_pending_uploads(f.h) == 0
+    assert L.fosphor_amd_process_uploaded(f.h, None) == -errno.EINVAL
+    assert L.fosphor_amd_upload_pinned(f.h, base, a) == 0				# 48 spectra
+    assert L.fosphor_amd_upload_pinned(f.h, base + 8 * a, b) == 0			# one batch
+    assert L.fosphor_amd_pending_uploads(f.h) == 2
+    assert L.fosphor_amd_upload_pinned(f.h, base + 8 * (a + b), b) == -errno.EBUSY
+    assert L.fosphor_amd_upload_pinned(f.h, base, 1024 * 1024 + 16 * 1024) == -errno.EINVAL	# beyond a batch: whole batches only
+    got = C.c_int()
+    assert L.fosphor_amd_process_uploaded(f.h, C.byref(got)) == 0 and got.value == a
+    assert o.process(x[:a]) == 0
+    assert L.fosphor_amd_process_uploaded(f.h, C.byref(got)) == 0 and got.value == b
+    assert o.process(x[a:a + b], nthreads=8) == 0
+    f.draw()
+    compare_state(f, o, "two pending uploads")
+    # three whole batches in one call == three calls (the middle one through process_pinned, which takes pending uploads first)
+    assert L.fosphor_amd_upload_pinned(f.h, base + 8 * (a + b), 3 * b) == 0
+    assert L.fosphor_amd_process_pinned(f.h, base + 8 * (a + 4 * b), b) == 0
+    assert L.fosphor_amd_pending_uploads(f.h) == 0
+    for k in range(1, 5):
+        assert o.process(x[a + k * b:a + (k + 1) * b], nthreads=8) == 0
+    f.draw()
+    compare_state(f, o, "three batches in one call, then one")
+    f.close()
+
+
 def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built):
     """The sink fed from a native thread in large work() calls (helper-thread copies, several FIFO regions in
     flight, regions discarded on their own upload events): every sample is processed exactly once and the final
