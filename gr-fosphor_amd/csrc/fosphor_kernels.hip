@@ -1368,7 +1368,22 @@ void k1w_fft_bin(const K1Params p)
  * for its lifetime (registers / two small LDS tables), ~40 % fewer instructions per sample.
  *
  * Bin indices: 512 bins need 9 bits.  The low 8 bits go out like the 1024-point path's (one dword = 4 consecutive spectra of
- * a column), the 9th as one bit per spectrum in a dword per (tile, column): 1.125 B per sample instead of 2. */
+ * a column), the 9th as one bit per spectrum in a dword per (tile, column): 1.125 B per sample instead of 2.
+ *
+ * THE LOOP IS SKEWED ("C5, round 4", has the measurement behind every choice).  A spectrum's blocks make a round
+ * trip store -> L2 -> cluster barrier -> load; with the loop in program order all eight waves of a CU sat through it (132 of 326 us).
+ * Instead the same threads run stage A of spectrum u + 1 meanwhile: its first pass between the stores of spectrum u and their
+ * s_waitcnt vmcnt(0), its wave-internal transpose and pass-2 twiddle products between the arrival at the cluster barrier and
+ * everybody else's, its pass-2 butterflies beside the loads of the intermediate.  What the in-order return of a wave's loads
+ * dictates around it:
+ *   - the fp16 IQ of spectrum u + 3 is requested (LDS-DMA, two 32 KiB buffers) only once the loads of the intermediate have been
+ *     used: a request to HBM ahead of them would delay them;
+ *   - that LDS-DMA is issued by hand (inline asm): the compiler parks every barrier and LDS read that follows an LDS-DMA it knows
+ *     about behind s_waitcnt vmcnt(0); the reads of the buffer sit behind an explicit vmcnt(0) of the requesting wave + a barrier;
+ *   - work-group barriers are s_waitcnt lgkmcnt(0) + s_barrier (wg_barrier_lds): __syncthreads() would drain vmcnt;
+ *   - the polls of the cluster counters are loads too: the "has everybody read the intermediate" poll is made by the last wave,
+ *     which requests no IQ, before its epilogue's stores;
+ *   - the exact path's threshold table sits in LDS (ds_read has its own counter). */
 
 /* X[jj] of dft16 sits in r[bitrev4(jj)] */
 #define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))

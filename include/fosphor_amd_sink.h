@@ -9,13 +9,19 @@
  * mouse callbacks to execute_ui_action().  INTEGRATION.md shows the wrapper.
  *
  * Differences from the reference, all on purpose:
- *   - the FIFO lives in pinned host memory and fosphor_amd_process_pinned() DMAs straight out of
- *     it; several regions are in flight at once and a region is read_discard()ed only when the event
- *     behind ITS copy has completed (checked without blocking; the per-frame fosphor_draw is the only
- *     wait).  The reference enqueues a non-blocking write from the FIFO and discards immediately
- *     (cl.c:903-910 vs base_sink_c_impl.cc:168-174): a latent race, not reproduced;
- *   - work() splits copies of 128 Ki samples and more over a few helper threads (one core's memcpy is
- *     ~1.5 GSamples/s, a PCIe Gen5 x16 link carries ~6.5);
+ *   - the FIFO lives in pinned host memory and the uploads DMA straight out of it, on a stream of
+ *     their own; several regions are in flight at once and a region is read_discard()ed only when the
+ *     event behind ITS copy has completed (checked without blocking).  A pass of render() queues the
+ *     kernels of what the pass before uploaded (fosphor_amd_process_uploaded), then the next uploads
+ *     (fosphor_amd_upload_pinned), then draws: the per-frame fosphor_draw waits for kernels only and
+ *     the link works on across it.  The reference enqueues a non-blocking write from the FIFO and
+ *     discards immediately (cl.c:903-910 vs base_sink_c_impl.cc:168-174): a latent race, not reproduced;
+ *   - with a FIFO of 4 Mi samples and more a call carries several whole 1024-spectrum batches (up to 8;
+ *     applied one after the other like so many calls): the host's time per call, not the link, bounded
+ *     the reference's one-batch-per-call loop (base_sink_c_impl.cc:157-158);
+ *   - work() splits copies of 128 Ki samples and more over 8 threads with non-temporal stores (one
+ *     core's memcpy is ~1.5 GSamples/s, a PCIe Gen5 x16 link carries 7.9); a source that can write into
+ *     the ring itself uses write_prepare() / write_commit() and no host copy is left;
  *   - no GL context: "visible" only decides whether render() synchronises (fosphor_draw) per frame;
  *   - set_fft_window takes the 1024 taps (gr::fft::window::build is GNU Radio's, the caller's).
  */

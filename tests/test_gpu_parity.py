@@ -1186,7 +1186,7 @@ def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built)
     for k in range(0, n_spec, 512):
         o.process(x[k * 1024:(k + 512) * 1024], nthreads=8)
     assert_close(wf, o.waterfall, "sink waterfall after a native feed")
-    # a rate, not only a count: the same samples again, several times (PCIe-inclusive; 4.65 GSamples/s measured with a 16 Mi
+    # a rate, not only a count: the same samples again, several times (PCIe-inclusive; round 3: 4.65 GSamples/s measured with a 16 Mi
     # FIFO on an idle box -- the floor here is a sixth of that, for a shared box and this 4 Mi FIFO)
     reps = 8
     dt = L.fosphor_amd_sink_feed(s, flat.ctypes.data, n_spec * 1024, 1 << 20, reps)
