@@ -338,7 +338,7 @@ static __device__ __forceinline__ void load_iq16(v2f (&x)[16], const float2 *__r
 }
 #define K1_LANE_SRC(lane) (2 * (lane))
 
-template <bool WRITE_FFT>
+template <bool WRITE_FFT, bool NB256 = false>	/* NB256: 256 bins -- the saturating conversion of the bin byte IS the clamp at n_bins - 1 */
 __global__ __launch_bounds__(256, K1_WAVES_PER_SIMD)
 void k1_fft_bin(const K1Params p)
 {
@@ -545,7 +545,7 @@ void k1_fft_bin(const K1Params p)
 				const float r = bin_fast(x[m].x, x[m].y, bk, &l2[m], &ab);
 				amb = amb > ab ? amb : ab;			/* v_max_u32: NaN / inf propagate */
 				if (!(K1_DBG_EPI & 8))
-					pack[m] = pack_bin(r, top, (uint32_t)u, pack[m]);
+					pack[m] = NB256 ? __builtin_amdgcn_cvt_pk_u8_f32(r, (uint32_t)u, pack[m]) : pack_bin(r, top, (uint32_t)u, pack[m]);
 				else
 					pack[m] ^= __float_as_uint(r);
 			}
@@ -1994,9 +1994,12 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 	if (blocks > max_blocks)
 		blocks = max_blocks;		/* persistent: 2 work-groups per CU */
 	if (p.fft_out)
-		hipLaunchKernelGGL(k1_fft_bin<true>, dim3(blocks), dim3(256), 0, s, p);
+		hipLaunchKernelGGL((k1_fft_bin<true, false>), dim3(blocks), dim3(256), 0, s, p);
 	else
-		hipLaunchKernelGGL(k1_fft_bin<false>, dim3(blocks), dim3(256), 0, s, p);
+		if (p.n_bins == 256)
+			hipLaunchKernelGGL((k1_fft_bin<false, true>), dim3(blocks), dim3(256), 0, s, p);
+		else
+			hipLaunchKernelGGL((k1_fft_bin<false, false>), dim3(blocks), dim3(256), 0, s, p);
 	return hipGetLastError();
 }
 
