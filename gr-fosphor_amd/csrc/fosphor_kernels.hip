@@ -1211,6 +1211,9 @@ void k1w_fft_bin(const K1Params p)
 	for (int g = 0; g < p.tile; g++) {
 		const int t = t0 + g;
 		const bool have_prev = g > 0;			/* uniform */
+		/* The two waves of a SIMD (waves w and w + 4 of the work-group) run their epilogue pieces on opposite sides of the barrier:
+		 * one computes while the other waits for its LDS loads, instead of all eight moving from LDS to VALU and back together */
+		const bool late = (__builtin_amdgcn_readfirstlane(th >> 6) & 4) != 0;
 		v2f x[16];
 		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
 
@@ -1255,8 +1258,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
 		}
-		if (have_prev) K1W_EPI(0, 6, t - 1);
+		if (have_prev && !late) K1W_EPI(0, 6, t - 1);
 		wg_barrier_lds();
+		if (have_prev && late) K1W_EPI(0, 6, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab0[rd + 512 * m];		/* item th + 512 v reads e = i + 1024 j = th + 512 (v + 2 j) */
@@ -1273,8 +1277,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab1[(st2 ^ (jj | (8 * (jj & 1)) | (16 * (jj >> 1)))) + 4096 * v] = r[R8_PERM(jj)];
 		}
-		if (have_prev) K1W_EPI(6, 11, t - 1);
+		if (have_prev && !late) K1W_EPI(6, 11, t - 1);
 		wg_barrier_lds();
+		if (have_prev && late) K1W_EPI(6, 11, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab1[rd + 512 * m];
@@ -1291,8 +1296,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(st3 ^ ((8 * jj) & 15)) + 64 * jj + 4096 * v] = r[R8_PERM(jj)];
 		}
-		if (have_prev) K1W_EPI(11, 16, t - 1);
+		if (have_prev && !late) K1W_EPI(11, 16, t - 1);
 		wg_barrier_lds();
+		if (have_prev && late) K1W_EPI(11, 16, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab0[rd + 512 * m];
