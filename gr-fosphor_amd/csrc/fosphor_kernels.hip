@@ -2395,9 +2395,13 @@ void k3_merge(const K3Params p)
 
 	/* the (d, e) table of the 16-bit path sits in LDS: loaded once per work-group, which then strides
 	 * over the cells (the grid is capped, so a 128 MiB state does not reload it 131 072 times) */
-	__shared__ float2 rise_lds[MODE == 0 ? 1025 : 1];
-	if (MODE == 0) {
-		for (int i = threadIdx.x; i <= p.batch && i < 1025; i += 256)
+	/* (long batches, MODE 3: in LDS as well up to 4096 spectra -- a look-up in memory is one more dependent round trip per batch
+	 * and cell; longer batches read it from memory) */
+	constexpr int kRiseLds = (MODE == 0) ? 1025 : (MODE == 3 && !SPARSE) ? 4097 : 1;
+	__shared__ float2 rise_lds[kRiseLds];
+	const bool rise_in_lds = (MODE == 0) || (MODE == 3 && !SPARSE && p.batch < kRiseLds);
+	if (rise_in_lds) {
+		for (int i = threadIdx.x; i <= p.batch && i < kRiseLds; i += 256)
 			rise_lds[i] = p.rise[i];
 		__syncthreads();
 	}
@@ -2509,6 +2513,56 @@ void k3_merge(const K3Params p)
 		return;
 	}
 
+	if (MODE == 3 && !SPARSE && p.n_batches <= 4) {
+		/* Long batches come a few per launch (4 at N = 8192): too few for the batches-in-flight scheme below to hide anything, and a
+		 * thread that walks its cells one after the other pays a memory round trip per cell.  FOUR CELLS IN FLIGHT per thread instead:
+		 * their histogram values and all their counts are requested together. */
+		constexpr int R = 4;
+		const int stride = gridDim.x * 256;
+		const int nb = p.n_bins, fe = p.n_batches;
+		const int pairs = cells >> 1;		/* a dword of the slabs = columns c and c + 32 of one (slab, bin) */
+		const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(p.hc16);
+		for (int base = blockIdx.x * 256 + threadIdx.x; base < pairs; base += R * stride) {
+			int hidx[R]; float hv0[R][2]; uint32_t hc[R][4];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const int g = base + r * stride;
+				const bool ok = g < pairs;
+				const int gg = ok ? g : base;
+				const int slab = gg / (nb * 32);
+				const int rem = gg - slab * nb * 32;
+				hidx[r] = ok ? (rem >> 5) * p.n + slab * 64 + (rem & 31) : -1;
+				hv0[r][0] = p.hist[ok ? hidx[r] : 0];
+				hv0[r][1] = p.hist[ok ? hidx[r] + 32 : 0];
+#pragma unroll
+				for (int f = 0; f < 4; f++)
+					hc[r][f] = (f < fe) ? __builtin_nontemporal_load(&hc32[(size_t)(p.dbg_same ? 0 : f) * pairs + gg]) : 0u;
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					float hv = hv0[r][h];
+#pragma unroll
+					for (int f = 0; f < 4; f++) {
+						const uint32_t c16 = h ? (hc[r][f] >> 16) : (hc[r][f] & 0xffffu);
+						if (f < fe && !((hv <= 0.01f) && (c16 == 0))) {	/* display.cl:237-238 */
+							const float2 de = rise_in_lds ? rise_lds[c16] : p.rise[c16];
+							hv = (hv - de.x) * de.y + de.x;			/* display.cl:247 */
+							hv = (hv < 0.0f) ? 0.0f : hv;			/* clamp, display.cl:250 */
+							hv = (1.0f < hv) ? 1.0f : hv;
+						}
+					}
+					if (hidx[r] >= 0 && __float_as_uint(hv) != __float_as_uint(hv0[r][h]))
+						p.hist[hidx[r] + 32 * h] = hv;	/* cold cells (display.cl:237-238) keep their line clean */
+				}
+			}
+		}
+		for (int x = blockIdx.x * 256 + threadIdx.x; x < p.n; x += stride)
+			update_column(x);
+		return;
+	}
+
 	for (int gid = blockIdx.x * 256 + threadIdx.x; gid < cells + p.n; gid += gridDim.x * 256) {
 	if (MODE == 0 || MODE == 3) {
 		/* 16-bit slab-major counts as K2 leaves them ([slab of 64 columns][bin][32] dwords, columns
@@ -2535,17 +2589,34 @@ void k3_merge(const K3Params p)
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
-							const float2 de = (MODE == 0) ? rise_lds[hc[u]] : p.rise[hc[u]];
+							const float2 de = rise_in_lds ? rise_lds[hc[u]] : p.rise[hc[u]];
 							hv = (hv - de.x) * de.y + de.x;		/* display.cl:247 */
 							hv = (hv < 0.0f) ? 0.0f : hv;		/* clamp, display.cl:250 */
 							hv = (1.0f < hv) ? 1.0f : hv;
 						}
 					}
 				}
+				/* (launches of fewer than 8 batches -- 4 at N = 8192 -- : the counts of what is left requested together as well) */
+				if (f + 4 <= fe) {
+					uint32_t hc[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++)
+						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						if (!((hv <= 0.01f) && (hc[u] == 0))) {
+							const float2 de = rise_in_lds ? rise_lds[hc[u]] : p.rise[hc[u]];
+							hv = (hv - de.x) * de.y + de.x;
+							hv = (hv < 0.0f) ? 0.0f : hv;
+							hv = (1.0f < hv) ? 1.0f : hv;
+						}
+					}
+					f += 4;
+				}
 				for (; f < fe; f++) {
 					const uint32_t hc = (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid];
 					if (!((hv <= 0.01f) && (hc == 0))) {
-						const float2 de = (MODE == 0) ? rise_lds[hc] : p.rise[hc];
+						const float2 de = rise_in_lds ? rise_lds[hc] : p.rise[hc];
 						hv = (hv - de.x) * de.y + de.x;
 						hv = (hv < 0.0f) ? 0.0f : hv;
 						hv = (1.0f < hv) ? 1.0f : hv;
@@ -2701,8 +2772,8 @@ hipError_t launch_k3(const K3Params &p, hipStream_t s)
 	}
 	if (p.hc16 && p.batch <= 1024)
 		hipLaunchKernelGGL(k3_merge<0>, dim3(blocks), dim3(256), 0, s, p);
-	else if (p.hc16)
-		hipLaunchKernelGGL(k3_merge<3>, dim3(blocks), dim3(256), 0, s, p);
+	else if (p.hc16)	/* (each work-group loads the 32 KiB table: four per CU stride over the cells) */
+		hipLaunchKernelGGL(k3_merge<3>, dim3(p.batch <= 4096 && blocks > 1024 ? 1024 : blocks), dim3(256), 0, s, p);
 	else if (p.rise)
 		hipLaunchKernelGGL(k3_merge<1>, dim3(blocks), dim3(256), 0, s, p);
 	else
