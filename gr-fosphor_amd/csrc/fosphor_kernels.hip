@@ -268,6 +268,9 @@ struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
 				 * 16 no bin-index stores, 32 sixteen LDS atomics per spectrum on a dummy counter array (what counting inside K1
 				 * would issue): the probe builds of profiles/r04_ceiling.md (tools/r04_ceiling_build.sh) */
 #endif
+#ifndef K1_LATE_BINS
+#define K1_LATE_BINS 1			/* 0: the bin dwords of a quad stored where the quad ends (A/B builds) */
+#endif
 #ifndef K1_THR_LDS
 #define K1_THR_LDS 1			/* 0: the N = 1024 kernel reads the thresholds from memory (A/B builds) */
 #endif
@@ -420,12 +423,36 @@ void k1_fft_bin(const K1Params p)
 		vmax[m] = vmax_init;
 	}
 
-	for (int g0 = 0; g0 < p.tile; g0 += 4) {
-		uint32_t pack[16];
+	/* The bin dwords of a quad of spectra are stored one window multiply LATER than they are complete: the wait for the prefetched IQ at
+	 * the top of a spectrum is an s_waitcnt vmcnt(0) (the number of stores behind the loads varies, so the compiler cannot count them out),
+	 * and stores issued behind those loads -- at the end of the previous spectrum -- made every fourth spectrum wait for its own stores'
+	 * acknowledgements.  Stores issued AHEAD of the next prefetch are older than the loads the wave waits for next. */
+	uint32_t pack[16];
+#pragma unroll
+	for (int m = 0; m < 16; m++)
+		pack[m] = 0;
+	int pend_row = -1;			/* row of p.bins the bytes in pack belong to, or -1 (uniform) */
+	auto flush_pack = [&]() {
+		uint32_t *dst = p.bins + (size_t)pend_row * kN + lane;
+		if (K1_DBG_EPI & 16) {
+			uint32_t any = 0;			/* keep the values alive without the stores */
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				any |= pack[m];
+			if (any == 0xdeadbeefu)
+				dst[0] = any;
+		} else {
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				dst[64 * m] = pack[m];
+		}
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			pack[m] = 0;
+		pend_row = -1;
+	};
 
+	for (int g0 = 0; g0 < p.tile; g0 += 4) {
 #pragma unroll 1
 		for (int u = 0; u < 4; u++) {
 			const int t = t0 + g0 + u;
@@ -440,6 +467,8 @@ void k1_fft_bin(const K1Params p)
 				x[2 * k + 1] = mul_bcast_hi(xn[2 * k + 1], w);
 			}
 
+			if (K1_LATE_BINS && u == 0 && pend_row >= 0)
+				flush_pack();		/* the previous quad's bin dwords: behind the wait above, ahead of the prefetch below */
 			/* prefetch the next spectrum this wave will process */
 			{
 				const bool last = (g0 + u + 1 == p.tile);
@@ -595,21 +624,13 @@ void k1_fft_bin(const K1Params p)
 		}
 
 		K1_STAMP(5);			/* 4th epilogue (the first three land in 7) */
-		/* 4 spectra x 1 column per dword, coalesced 256 B per instruction */
-		uint32_t *dst = p.bins + (size_t)((t0 + g0) >> 2) * kN + lane;
-		if (K1_DBG_EPI & 16) {
-			uint32_t any = 0;			/* keep the values alive without the stores */
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				any |= pack[m];
-			if (any == 0xdeadbeefu)
-				dst[0] = any;
-		} else {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				dst[64 * m] = pack[m];
-		}
+		/* 4 spectra x 1 column per dword, coalesced 256 B per instruction: stored at the top of the next quad (or below) */
+		pend_row = (t0 + g0) >> 2;
+		if (!K1_LATE_BINS)
+			flush_pack();
 	}
+	if (pend_row >= 0)
+		flush_pack();
 
 	/* leave the log2 domain: pwr = log10|X| = l2 * log10(2)/2; an untouched max is exactly -1000 */
 	float2 *pp = p.partial + (size_t)tile * kN + lane;
