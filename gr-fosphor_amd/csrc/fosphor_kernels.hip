@@ -1175,6 +1175,10 @@ void k1w_fft_bin(const K1Params p)
 	 * (display.cl:136-150,161-168).  Per column, nothing carried from column to column: it is cut into three pieces that
 	 * run between the LDS stores of the NEXT spectrum's exchanges and the barrier behind them, i.e. while this wave
 	 * would otherwise wait for the slowest one. */
+#ifndef K1W_P1
+#define K1W_P1 6		/* the three epilogue pieces: columns [0, P1), [P1, P2), [P2, 16) of a thread (A/B builds) */
+#define K1W_P2 11
+#endif
 #define K1W_EPI(M0, M1, tp) do { \
 		const bool _row = ((tp) >= p.wf_first); \
 		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + th; \
@@ -1279,9 +1283,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
 		}
-		if (have_prev && !late) K1W_EPI(0, 6, t - 1);
+		if (have_prev && !late) K1W_EPI(0, K1W_P1, t - 1);
 		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(0, 6, t - 1);
+		if (have_prev && late) K1W_EPI(0, K1W_P1, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab0[rd + 512 * m];		/* item th + 512 v reads e = i + 1024 j = th + 512 (v + 2 j) */
@@ -1298,9 +1302,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab1[(st2 ^ (jj | (8 * (jj & 1)) | (16 * (jj >> 1)))) + 4096 * v] = r[R8_PERM(jj)];
 		}
-		if (have_prev && !late) K1W_EPI(6, 11, t - 1);
+		if (have_prev && !late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
 		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(6, 11, t - 1);
+		if (have_prev && late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab1[rd + 512 * m];
@@ -1317,9 +1321,9 @@ void k1w_fft_bin(const K1Params p)
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(st3 ^ ((8 * jj) & 15)) + 64 * jj + 4096 * v] = r[R8_PERM(jj)];
 		}
-		if (have_prev && !late) K1W_EPI(11, 16, t - 1);
+		if (have_prev && !late) K1W_EPI(K1W_P2, 16, t - 1);
 		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(11, 16, t - 1);
+		if (have_prev && late) K1W_EPI(K1W_P2, 16, t - 1);
 #pragma unroll
 		for (int m = 0; m < 16; m++)
 			x[m] = slab0[rd + 512 * m];
