@@ -1127,7 +1127,13 @@ void k1w_fft_bin(const K1Params p)
 	 * to, a barrier lies between those stores and the last loads from it */
 	v2f *slab0 = reinterpret_cast<v2f *>(smem_raw);
 	v2f *slab1 = slab0 + N;
-	v2f *twr = slab0 + 2 * N;		/* radix-2 twiddles [4096]: the last 32 KiB of the CU's 160 KiB */
+	/* behind the slabs: the exact-bin thresholds (n_bins + 1 <= 513 doubles).  The rare path that consults them runs in every other
+	 * wave-spectrum at 512 bins, and while one wave is in it the other seven wait at the next barrier: a look-up through the scalar cache
+	 * cost 29 us of 330 per launch (probe with an empty body: 301), ds_read costs less.  (The radix-2 twiddles that used to sit here are
+	 * eight per thread, fixed for its lifetime: registers.) */
+	typedef const __attribute__((address_space(3))) double *lds_cdp;
+	double *thr_g = reinterpret_cast<double *>(slab0 + 2 * N);
+	const lds_cdp thr_l = (lds_cdp)thr_g;
 
 	const int th = threadIdx.x;
 	const int ntiles = p.total / p.tile;
@@ -1140,11 +1146,14 @@ void k1w_fft_bin(const K1Params p)
 	/* ---- per-thread constants ------------------------------------------------ */
 	v2f win[8];			/* taps of elements (2 th, 2 th + 1) + 1024 j */
 	v2f tw8[7], tw64[7], tw512[7];	/* k = th & 7, th & 63, th (both items of a pair) */
+	v2f twr[8];			/* radix-2 twiddles k = th + 512 c */
 #pragma unroll
 	for (int j = 0; j < 8; j++) {
 		win[j] = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * j);
-		twr[th + 512 * j] = twg[p.tw_off[3] + th + 512 * j];
+		twr[j] = twg[p.tw_off[3] + th + 512 * j];
 	}
+	for (int e = th; e <= p.n_bins && e < 520; e += TH)
+		thr_g[e] = p.thr[e];
 	__syncthreads();
 #pragma unroll
 	for (int n = 0; n < 7; n++) {
@@ -1200,7 +1209,7 @@ void k1w_fft_bin(const K1Params p)
 				const float a = __builtin_fmaf(__builtin_fabsf(_l2[m - (M0)]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v))); \
 				if (!(a <= bk.amb)) { \
 					float nl2; \
-					_bn[m - (M0)] = bin_exact(xo[m].x, xo[m].y, _l2[m - (M0)], (int)_bn[m - (M0)], ThrScalar{ bk.thr }, bk.nb, &nl2); \
+					_bn[m - (M0)] = bin_exact(xo[m].x, xo[m].y, _l2[m - (M0)], (int)_bn[m - (M0)], thr_l, bk.nb, &nl2); \
 					_l2[m - (M0)] = nl2; \
 				} \
 			} \
@@ -1345,7 +1354,7 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 			for (int c = 0; c < 8; c++) {
 				v2f a = y[c];
-				v2f b = c_mul(y[c + 8], twr[th + 512 * c]);
+				v2f b = c_mul(y[c + 8], twr[c]);
 				DFT2(a, b);
 				xo[c] = a;
 				xo[c + 8] = b;
@@ -1973,7 +1982,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		const char *k1w_env = getenv("FOSPHOR_AMD_K1W");
 		const bool k1w_on = !(k1w_env && *k1w_env == '0');
 		if (k1w_on && !(p.hop & 1)) {
-			constexpr int ldsw = 2 * 8192 * 8 + 4096 * 8;	/* two slabs + the radix-2 twiddles: 160 KiB */
+			constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
 			static bool attr_w = false;
 			if (!attr_w) {
 				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1w_fft_bin<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
