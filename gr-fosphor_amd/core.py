@@ -193,6 +193,14 @@ class Fosphor:
         """False/0: off; True/1: hipEvents around every kernel; 2: around K1 only."""
         self.L.fosphor_amd_profile(self.h, 2 if enable == 2 and enable is not True else (1 if enable else 0))
 
+    def tune_placement(self, d_samples, n_batches, batch, max_tries=6):
+        """fosphor_amd_tune_placement: (re-allocations made, slowest set's twin us before, after)."""
+        b, a = C.c_float(), C.c_float()
+        rv = self.L.fosphor_amd_tune_placement(self.h, _ptr(d_samples), int(n_batches), int(batch), int(max_tries), C.byref(b), C.byref(a))
+        if rv < 0:
+            raise RuntimeError("fosphor_amd_tune_placement -> %d" % rv)
+        return rv, b.value, a.value
+
     def traffic_twin(self, d_samples, n_batches, batch, reps=20):
         """ms per launch of K1's memory traffic alone (include/fosphor_amd.h)"""
         ms = C.c_float()

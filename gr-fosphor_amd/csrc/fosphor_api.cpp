@@ -1950,6 +1950,83 @@ extern "C" int fosphor_amd_traffic_twin(struct fosphor *self, const void *d_samp
 	return 0;
 }
 
+/* Placement tuning.  On MI355X the same FFT launch runs in one of two states -- its bare memory traffic takes 98 or 109 us per 512 MiB of
+ * IQ -- and which one is a property of the ALLOCATIONS involved: the caller's IQ buffer against this instance's intermediate sets (bin
+ * indices + tile partials).  Re-allocating either re-rolls it (about even odds; offsets inside an allocation do not matter: measured up to
+ * 1 GiB; tools/twin_state.py).  This call measures the memory twin of the FFT kernel against `d_samples` for every intermediate set and
+ * re-allocates a set (keeping the rejected allocations until the end, so that the allocator hands out different memory) until its traffic
+ * runs at >= 6.0 TB/s or `max_tries` allocations have been tried, keeping the fastest.  us_before / us_after: the slowest set before and
+ * after (NULL allowed).  Returns the number of re-allocations made, or -EINVAL / -EIO.  Results never depend on it. */
+extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_samples, int n_batches, int batch, int max_tries,
+                                          float *us_before, float *us_after)
+{
+	const int total = n_batches * batch;
+	if (!self || !d_samples || total < 16 || total > self->max_spectra || self->log2n != 10 || self->bins16 || max_tries < 1)
+		return -EINVAL;
+	if (fosphor_amd_finish(self) < 0)
+		return -EIO;
+	const size_t bins_bytes = (size_t)self->max_spectra * self->n * (self->bins16 ? 2 : 1);
+	size_t tiles_max = (size_t)self->max_spectra / 4;
+	const size_t part_bytes = sizeof(float2) * tiles_max * self->n;
+	/* what the twin moves per launch: the IQ, one byte of bin index per sample, the tile partials */
+	const double bytes = (double)total * self->n * 9.0 + (double)(total / pick_tile(self, total, batch)) * self->n * 8.0;
+	const float good_ms = (float)(bytes / 6.0e12 * 1e3);
+	std::vector<void *> rejected;
+	int reallocs = 0;
+	float worst_before = 0.0f, worst_after = 0.0f;
+	uint32_t *const cur_bins = self->d_bins;
+	float2 *const cur_part = self->d_partial;
+	int cur_set = 0;
+	for (int i = 0; i < kSets; i++)
+		if (self->d_bins_pp[i] == cur_bins) cur_set = i;
+	for (int i = 0; i < self->n_sets; i++) {
+		float best = 0.0f;
+		for (int t = 0; t < max_tries; t++) {
+			uint32_t *nb = self->d_bins_pp[i];
+			float2 *np = self->d_partial_pp[i];
+			if (t > 0) {
+				if (hipMalloc((void **)&nb, bins_bytes) != hipSuccess)
+					break;
+				if (hipMalloc((void **)&np, part_bytes) != hipSuccess) {
+					(void)hipFree(nb);
+					break;
+				}
+			}
+			uint32_t *const ob = self->d_bins_pp[i];
+			float2 *const op = self->d_partial_pp[i];
+			self->d_bins_pp[i] = nb; self->d_partial_pp[i] = np;
+			self->d_bins = nb; self->d_partial = np;
+			float ms = 0.0f;
+			if (fosphor_amd_traffic_twin(self, d_samples, n_batches, batch, 8, &ms) != 0) {
+				self->d_bins_pp[i] = ob; self->d_partial_pp[i] = op;
+				if (t > 0) { (void)hipFree(nb); (void)hipFree(np); }
+				break;
+			}
+			if (t == 0) {
+				best = ms;
+				if (ms > worst_before) worst_before = ms;
+			} else if (ms < best) {
+				rejected.push_back(ob); rejected.push_back(op);		/* the new pair is the better one */
+				best = ms;
+				reallocs++;
+			} else {
+				self->d_bins_pp[i] = ob; self->d_partial_pp[i] = op;	/* keep what we had */
+				rejected.push_back(nb); rejected.push_back(np);
+			}
+			if (best <= good_ms)
+				break;
+		}
+		if (best > worst_after) worst_after = best;
+	}
+	for (void *q : rejected)
+		(void)hipFree(q);
+	self->d_bins = self->d_bins_pp[cur_set];
+	self->d_partial = self->d_partial_pp[cur_set];
+	if (us_before) *us_before = worst_before * 1e3f;
+	if (us_after) *us_after = worst_after * 1e3f;
+	return reallocs;
+}
+
 extern "C" void *fosphor_amd_stream(struct fosphor *self)
 {
 	return self ? (void *)self->stream : NULL;

@@ -248,6 +248,17 @@ void *fosphor_amd_stream2(struct fosphor *self);
  * replaces the reference's blocking upload, lib/fosphor/cl.c:903-910. */
 void *fosphor_amd_upload_stream(struct fosphor *self);
 
+/* Placement tuning (1024-point instances with 8-bit bin indices).  On MI355X one and the same FFT launch runs in one of two
+ * states -- its bare memory traffic takes 98 or 109 us per 512 MiB of IQ -- and which one is decided by the ALLOCATIONS involved:
+ * the caller's IQ buffer against the instance's intermediate sets.  Re-allocating either side re-rolls it at about even odds.
+ * This call times the FFT kernel's memory traffic against `d_samples` (n_batches x batch spectra, as for
+ * fosphor_amd_process_device) for every intermediate set and re-allocates a set until its traffic runs at 6 TB/s or
+ * `max_tries` allocations have been tried, keeping the fastest.  *us_before / *us_after: the slowest set's time per launch
+ * before and after (NULL allowed).  Returns the number of sets' allocations replaced, -EINVAL or -EIO.  Results never depend on
+ * it; call it once, after the instance and the input buffer exist (a few milliseconds). */
+int fosphor_amd_tune_placement(struct fosphor *self, const void *d_samples, int n_batches, int batch, int max_tries,
+                               float *us_before, float *us_after);
+
 /* Library identification: "fosphor_amd <version> gfx950". */
 const char *fosphor_amd_version(void);
 

@@ -1123,6 +1123,35 @@ def test_sink_zero_copy_feed(amd, torch_cuda, oracle_built):
     L.fosphor_amd_sink_free(s)
 
 
+def test_placement_tuning_leaves_results_alone(amd, torch_cuda, oracle_built):
+    """fosphor_amd_tune_placement re-allocates intermediate sets (the FFT kernel's memory traffic runs in one of two states, decided by
+    the allocations involved); whatever it replaces, the state that has been accumulated and the results of later calls are the
+    oracle's.  It reports sane times and refuses what the traffic twin cannot time."""
+    import errno
+    torch = torch_cuda
+    L = amd.load()
+    f = amd.Fosphor(n_bins=256, max_spectra=4096, max_batches=4)
+    o = Oracle(n_bins=256)
+    x = add_tone(gaussian_iq(6 * 1024 * 1024, 123), 0.15, 0.11).reshape(6, 1024 * 1024, 2)
+    d = torch.from_numpy(x).cuda()
+    assert f.process_device(d[:2], 2, 1024) == 0
+    for k in range(2):
+        assert o.process(x[k], nthreads=8) == 0
+    replaced, before, after = f.tune_placement(d[:4], 4, 1024, max_tries=4)		# between two calls: state must survive
+    assert 0 <= replaced <= 3 * 3 and 0.0 < after <= before * 1.02 and before < 1000.0
+    assert f.process_device(d[2:], 4, 1024) == 0
+    for k in range(2, 6):
+        assert o.process(x[k], nthreads=8) == 0
+    f.draw()
+    compare_state(f, o, "across a placement tuning")
+    assert L.fosphor_amd_tune_placement(f.h, d.data_ptr(), 8, 1024, 4, None, None) == -errno.EINVAL	# more than max_spectra
+    assert L.fosphor_amd_tune_placement(f.h, d.data_ptr(), 4, 1024, 0, None, None) == -errno.EINVAL
+    f.close()
+    g = amd.Fosphor(n_bins=512, max_spectra=1024)						# 16-bit indices: the twin does not model them
+    assert L.fosphor_amd_tune_placement(g.h, d.data_ptr(), 1, 1024, 2, None, None) == -errno.EINVAL
+    g.close()
+
+
 def test_upload_and_kernels_in_two_steps(amd, torch_cuda, oracle_built):
     """fosphor_amd_upload_pinned / fosphor_amd_process_uploaded (what the sink's frame loop calls): two uploads may be pending, a
     third is refused with -EBUSY, the kernels are queued oldest first, and a call that carries several whole batches is applied like
