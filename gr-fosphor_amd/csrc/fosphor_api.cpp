@@ -2013,7 +2013,8 @@ extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_sa
 				self->d_bins_pp[i] = ob; self->d_partial_pp[i] = op;	/* keep what we had */
 				rejected.push_back(nb); rejected.push_back(np);
 			}
-			if (best <= good_ms)
+			static const int tune_all = [] { const char *e = getenv("FOSPHOR_AMD_DBG_TUNE_ALL"); return e ? atoi(e) : 0; }();
+			if (best <= good_ms && t + 1 >= tune_all)
 				break;
 		}
 		if (best > worst_after) worst_after = best;

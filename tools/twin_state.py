@@ -38,5 +38,5 @@ for k in range(10):
         r, b, a = f.tune_placement(iq, sub, spb)
         res.append("%.0f->%.0f(%d)" % (b, a, r))
     else:
-        res.append("%.0f" % (f.traffic_twin(iq, sub, spb, reps=20) * 1e3))
+        res.append("%.1f" % (f.traffic_twin(iq, sub, spb, reps=40) * 1e3))
 print("%s %s: twin us = %s" % (mode, what, " ".join(res)))
