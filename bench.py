@@ -82,8 +82,8 @@ def parse():
     ap.add_argument("--no-traffic-twin", action="store_true")
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="take the allocations as they come (default: fosphor_amd_tune_placement once, untimed, before the pre-conditioning)")
-    ap.add_argument("--placement-candidates", type=int, default=4,
-                    help="batch mode: instances (= sets of allocations) tried before the run; the fastest over 24 untimed steps is kept")
+    ap.add_argument("--placement-candidates", type=int, default=1,
+                    help="batch mode: instances (= sets of allocations) tried before the run; the fastest over 48 untimed steps is kept")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the informational K2/K3 and isolated-K1 passes")
     ap.add_argument("--strict-ordering", action="store_true", help="keep stream ordering between calls (default: relaxed, "
                     "the input ring is never rewritten)")
@@ -269,12 +269,14 @@ def main():
         tune(f)
         if mode == "batch" and args.placement_candidates > 1:
             # The twin sees the FFT kernel's own pair of streams; the count and merge kernels have theirs.  What decides is the pipeline:
-            # a few candidate instances (each a fresh set of allocations), 24 untimed steps each, the fastest stays.
+            # a few candidate instances (each a fresh set of allocations), 48 untimed steps each, the fastest stays.
             def quick_rate():
-                run_steps(8); sync()
+                t_w = time.perf_counter()
+                while time.perf_counter() - t_w < min(args.precondition, 0.2):	# (every candidate warmed alike: clocks, first touches)
+                    run_steps(4); sync()
                 t_q = time.perf_counter()
-                run_steps(24); sync()
-                return 24 * F * samples_per_batch / (time.perf_counter() - t_q) / 1e6
+                run_steps(48); sync()
+                return 48 * F * samples_per_batch / (time.perf_counter() - t_q) / 1e6
             cands.append((quick_rate(), f))
             for c in range(1, args.placement_candidates):
                 f = gr_fosphor_amd.Fosphor(stream=stream, **kw)
