@@ -242,7 +242,7 @@ def main():
     # re-allocates its sets until the traffic runs at 6 TB/s (fosphor_amd_tune_placement); if none does, the IQ ring is the unlucky side
     # and is allocated again (same distribution, the generator's next numbers).
     placement = None
-    if cfg["log2n"] == 10 and bins <= 256 and not args.no_placement_tuning:
+    if cfg["log2n"] == 10 and bins <= 256 and not args.no_placement_tuning and F >= 16:	# (a launch long enough for its time to be bandwidth)
         sub_t = min(F, 64)
         n_t = sub_t * samples_per_batch
         good_us = (n_t * 9.0 + n_t / 64 * 8.0) / 6.0e12 * 1e6
