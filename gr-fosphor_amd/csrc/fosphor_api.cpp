@@ -1970,6 +1970,9 @@ extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_sa
 	const size_t part_bytes = sizeof(float2) * tiles_max * self->n;
 	/* what the twin moves per launch: the IQ, one byte of bin index per sample, the tile partials */
 	const double bytes = (double)total * self->n * 9.0 + (double)(total / pick_tile(self, total, batch)) * self->n * 8.0;
+	/* (a launch of less than 128 MiB is timed by its launch overhead, not by the memory behind it: measured, nothing replaced) */
+	if (bytes < 128.0 * 1048576.0)
+		max_tries = 1;
 	const float good_ms = (float)(bytes / 6.0e12 * 1e3);
 	std::vector<void *> rejected;
 	int reallocs = 0;
