@@ -136,7 +136,7 @@ sink_runtime::sink_runtime(int fifo_length)
     d_active(false), d_frozen(false), d_visible(true), d_draining(false),
     d_pending(0),
     d_have_window(false), d_frames(0), d_samples(0),
-    d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0),
+    d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0), d_batches_per_call(1),
     d_copy_gen(0), d_copy_pending(0), d_copy_sleepers(0), d_copy_quit(false)
 {
 	d_ui = ui_state{ 1024, 1024, 0, 3, false, 0.5, 0.2, 0.35f, 0.0, 1.0 };
