@@ -275,6 +275,19 @@ static void build_thresholds(double *thr, int nb, float hs, float ho)
  * the L2s when it is recorded, which costs microseconds between dependent kernels and sends the
  * consumer's reads to HBM.  Kernel boundaries keep their device-scope release/acquire.
  * (Events the HOST waits on for host-visible data -- staging, upload -- keep the default.) */
+/* Output streams of the 65536-point kernel (waterfall rows, bin indices) live in UNCACHED device memory: its clusters keep their
+ * intermediate in the XCD's L2 and every byte streamed through that L2 pushes intermediate lines out, to be written back to HBM although
+ * they are dead.  Uncached stores go past the L2: WRITE_SIZE per 1024-spectrum frame 649 -> 541 MiB at the same kernel time (DESIGN.md
+ * section 8; FOSPHOR_AMD_UC_OUTPUTS=0 for the A/B).  The other configurations have no such hot set and keep plain memory (the 8192-point
+ * kernel's index stores run 6 % slower uncached). */
+static hipError_t alloc_output(void **p, size_t bytes, bool uncached)
+{
+	const char *e = getenv("FOSPHOR_AMD_UC_OUTPUTS");
+	if (uncached && !(e && *e == '0') && hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess)
+		return hipSuccess;
+	return hipMalloc(p, bytes);
+}
+
 static unsigned dep_event_flags(void)
 {
 	const char *e = getenv("FOSPHOR_AMD_SYSFENCE");
@@ -438,7 +451,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_tw, sizeof(float2) * self->tw_len), "alloc twiddles");
 	HIP_TRY(hipMalloc((void **)&self->d_thr, sizeof(double) * (self->n_bins + 1)), "alloc thresholds");
 	for (int i = 0; i < 2; i++) {
-		HIP_TRY(hipMalloc((void **)&self->d_wf_pp[i], sizeof(float) * (size_t)self->wf_rows * self->n), "alloc waterfall");
+		HIP_TRY(alloc_output((void **)&self->d_wf_pp[i], sizeof(float) * (size_t)self->wf_rows * self->n, self->log2n == 16), "alloc waterfall");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_wf[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipEventCreateWithFlags(&self->ev_in, dep_event_flags()), "create event");
@@ -459,7 +472,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	HIP_TRY(hipMalloc((void **)&self->d_hist, sizeof(float) * (size_t)self->n_bins * self->n), "alloc histogram");
 	HIP_TRY(hipMalloc((void **)&self->d_spectrum, sizeof(float2) * 2 * self->n), "alloc spectrum");
 	for (int i = 0; i < kSets; i++) {
-		HIP_TRY(hipMalloc((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * self->n * (self->bins16 ? 2 : 1)), "alloc bin indices");
+		HIP_TRY(alloc_output((void **)&self->d_bins_pp[i], (size_t)self->max_spectra * self->n * (self->bins16 ? 2 : 1), self->log2n == 16), "alloc bin indices");
 		HIP_TRY(hipMalloc((void **)&self->d_partial_pp[i], sizeof(float2) * tiles_max * self->n), "alloc partials");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_k1_done[i], dep_event_flags()), "create event");
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_set_free[i], dep_event_flags()), "create event");
