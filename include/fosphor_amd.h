@@ -86,7 +86,10 @@ int fosphor_amd_finish(struct fosphor *self);
  *                                  which waits for it)
  * Pointers are device pointers.  histogram / spectrum / hitcount stay where they are until fosphor_release;
  * d_waterfall is one of two rings and must be re-queried after every process call (a call that rewrites
- * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering). */
+ * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering).
+ * At fft_len_log = 16 the waterfall rings are UNCACHED device memory (hipDeviceMallocUncached: the kernel's row stores must not
+ * pass through the L2 that holds its intermediate): any kernel or copy may read them, reads simply are not
+ * cached (FOSPHOR_AMD_UC_OUTPUTS=0 in the environment gives plain memory). */
 struct fosphor_amd_buffers
 {
 	float    *d_waterfall;
