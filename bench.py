@@ -56,7 +56,7 @@ CONFIGS = {
                text="C2: 1024-pt FFT, batch=1024 spectra, 1024x%(bins)d histogram + waterfall; one step = one "
                     "fosphor_amd_process_device call of %(bps)d such batches (%(msamp)d Mi samples, %(mib)d MiB of IQ), "
                     "sub-launched %(sub)d batches at a time, every batch with its own state update"),
-    "C3": dict(log2n=13, bins=512, spb=4096, bps=4, over=2, fp16=False,
+    "C3": dict(log2n=13, bins=512, spb=4096, bps=28, over=2, fp16=False,
                text="C3: 8192-pt FFT, 50 %% overlap (overlap_cc(8192, 2) fused into the read), batch=4096 spectra, "
                     "8192x%(bins)d histogram + waterfall; one step = one fosphor_amd_process_device_overlap call of "
                     "%(bps)d such batches (%(msamp)d Mi FFT'd samples)"),

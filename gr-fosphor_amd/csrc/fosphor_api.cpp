@@ -41,6 +41,12 @@ enum { ST_BOOTING = 0, ST_PENDING = 1, ST_READY = 2 };	/* cl.c:92-96 */
 static const int kMaxN = 65536;
 static const int kSets = 5;		/* intermediate (bin index / partial) sets in rotation */
 static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams */
+/* N = 8192, space sharing: the FFT kernel (one work-group per CU, every register of it) takes 224 CUs when a launch's tiles divide
+ * evenly among them, and the count / merge kernels of the launch before run on the 32 it leaves free -- the dispatcher fills CUs it
+ * finds empty, no CU mask involved (hardware masks that remove CUs unevenly from the shader engines unbalance a grid of CU-sized
+ * work-groups: tools/ubench/cu_mask_big.hip).  Measured at BASELINE C3: 333 -> 367-371 GSamples/s with 28 batches per call, 358
+ * with 14, 345 with 7; 232 / 240 CUs leave the tail too little (it becomes the longer side), 216: 356. */
+static const int kK1wShareCus = 224;
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
@@ -520,8 +526,9 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		/* N = 8192: the FFT kernel owns every CU's LDS and registers, so count and merge cannot run beside it either way; on one
 		 * stream the kernel boundaries are cheaper than cross-stream events (measured 286.6 / 287.8 / 287.1 against 286.1 / 284.7 /
 		 * 283.5 GSamples/s), and K1's busy time is no longer stretched by launches waiting for each other (0.363 vs 0.29-0.345). */
-		if (self->log2n == 13 && !(e && *e == '1'))
-			self->overlap = 0;
+		/* (round 4: the streams are back for N = 8192 -- with space sharing, kK1wShareCus, count and merge DO run beside the next FFT
+		 * launch; for launch shapes that cannot share, the streams cost 0.3 %: 326 against 327 GSamples/s.  FOSPHOR_AMD_OVERLAP=0:
+		 * one stream.) */
 		e = getenv("FOSPHOR_AMD_K1");
 		self->k1_variant = (e && *e == '2') ? 2 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
@@ -530,12 +537,17 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->alt = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_SETS");
 		self->n_sets = (e && atoi(e) >= 2 && atoi(e) <= kSets) ? atoi(e) : 3;
+		if (self->log2n == 13 && !getenv("FOSPHOR_AMD_K1_STREAMS"))
+			self->n_k1_streams = 1;		/* a second FFT launch in flight would take the CUs left to count / merge */
 		if (self->n_k1_streams == 1)
 			self->alt = 0;
 		e = getenv("FOSPHOR_AMD_SUB_LOG2");		/* tuning: log2 of the samples per sub-launch */
 		/* (N = 8192: the one-work-group-per-CU FFT kernel owns the whole LDS, so K2 cannot run beside it and a
 		 * smaller piece only adds serialised kernel boundaries: twice the default) */
-		self->sub_samples = 1LL << ((e && atoi(e) >= 14 && atoi(e) <= 34) ? atoi(e) : kSubSamplesLog2 + (self->log2n == 13 ? 1 : 0));
+		/* (round 4, N = 8192: 1 Gi samples -- up to 32 batches of 4096 spectra in one FFT launch: with space sharing a launch boundary
+		 * costs ~40 us, during which the count kernels of the finished launch and the work-groups of the next FFT launch compete for
+		 * the CUs) */
+		self->sub_samples = 1LL << ((e && atoi(e) >= 14 && atoi(e) <= 34) ? atoi(e) : (self->log2n == 13 ? 30 : kSubSamplesLog2));
 	}
 	HIP_TRY(hipMalloc((void **)&self->d_hc, sizeof(uint32_t) * (size_t)self->max_batches * self->n_bins * self->n), "alloc hit counts");
 	HIP_TRY(hipMalloc((void **)&self->d_hc_export, sizeof(uint32_t) * (size_t)self->n_bins * self->n), "alloc hit count view");
@@ -820,6 +832,10 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 		k1->dbg_k1h = dbg;
 	}
 	k1->iq_half = self->iq_half;
+	{
+		static const bool share = [] { const char *e = getenv("FOSPHOR_AMD_K1W_SHARE"); return !(e && *e == '0'); }();
+		k1->cus = (self->log2n == 13 && self->overlap && share && tile > 0 && (total / tile) % kK1wShareCus == 0) ? kK1wShareCus : 0;
+	}
 	if (k1->variant == 1 && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
 }
@@ -1067,6 +1083,15 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	if (sub_b > n_batches) sub_b = n_batches;
 	n_sub = (n_batches + sub_b - 1) / sub_b;
 	sub_b = (n_batches + n_sub - 1) / n_sub;
+	if (self->log2n == 13 && self->overlap && n_sub > 1) {
+		/* space sharing needs every piece's tiles to be a multiple of kK1wShareCus: pieces of whole `unit`s of batches where the
+		 * call allows it (tiles are 64 spectra or the batch: pick_tile) */
+		const int tpb = batch >= 64 ? batch / 64 : 1;
+		const int unit = kK1wShareCus / gcd_int(kK1wShareCus, tpb);
+		const int cap = (int)(self->sub_samples / ((long long)batch * self->n));
+		if (n_batches % unit == 0 && cap >= unit)
+			sub_b = cap / unit * unit;
+	}
 	use_alt = self->overlap && self->alt && device_call && (n_sub > 1 || self->relaxed);
 	if (self->log2n == 16 && self->k1h_fused)
 		use_alt = 0;		/* one fused FFT kernel at a time: its clusters own the counters and the intermediate */

@@ -57,6 +57,8 @@ struct K1Params {
 	float amb;			/* confident when |v - rint(v)| + kappa |l2| <= amb */
 	float kappa;			/* v_log_f32 error bound per unit of |log2 s|, through the slope binA */
 	float w;			/* 1 - alpha */
+	int   cus;			/* N = 8192: work-groups (= CUs) of the FFT launch when it leaves CUs to the count / merge kernels
+					 * (kK1wShareCus; the launch's tiles are a multiple of it), 0 = every CU */
 	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum (odd hops); 3: general N (N/8 threads per
 					 * spectrum, one LDS slab); 4: N = 65536 in two LDS stages */
 };

@@ -1992,7 +1992,10 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 					return e;
 				attr_w = true;
 			}
-			const int bw = tiles < 256 ? tiles : 256;	/* one 8-wave work-group per CU */
+			/* one 8-wave work-group per CU -- or per CU of the share the host leaves to this kernel (K1Params.cus: the count and
+			 * merge kernels of the previous launch run on the rest) */
+			const int cus = (p.cus > 0 && p.cus < 256 && tiles % p.cus == 0) ? p.cus : 256;
+			const int bw = tiles < cus ? tiles : cus;
 			if (p.fft_out)
 				hipLaunchKernelGGL(k1w_fft_bin<true>, dim3(bw), dim3(512), ldsw, s, p);
 			else
