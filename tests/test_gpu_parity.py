@@ -486,6 +486,36 @@ def test_c3_full_batch_properties(amd, torch_cuda, oracle_built):
     f.close(); f2.close()
 
 
+def test_c3_space_sharing_is_bit_identical(amd, torch_cuda):
+    """N = 8192, space sharing: a call whose tiles are a multiple of 224 -- here 14 batches of 1024
+    spectra = 448 tiles of 32 -- runs its FFT kernel on 224 work-groups and the count / merge kernels of the PREVIOUS call on
+    the CUs it leaves free.  Two such calls back to back (the second call's FFT kernel beside the first call's count and merge)
+    must leave exactly the state of the single-stream form (fosphor_amd_set_overlap(0): 256 work-groups, one kernel at a
+    time): same kernels, same order per cell, so every buffer bit for bit; and every column's counts sum to the batch."""
+    torch = torch_cuda
+    n, nb, over, B, F = 8192, 512, 2, 1024, 14
+    hop = n // over
+    xs = [add_tone(gaussian_iq((F * B - 1) * hop + n, 4242 + k), 0.05, 0.0313 + 0.01 * k) for k in range(2)]
+    ds = [torch.from_numpy(x).cuda() for x in xs]
+    res = []
+    for shared in (True, False):
+        f = amd.Fosphor(fft_len_log=13, n_bins=nb, max_spectra=F * B, max_batches=F)
+        if not shared:
+            assert f.set_overlap(False) == 0
+        for d in ds:
+            assert f.process_device_overlap(d, F, B, over) == 0
+        assert f.finish() == 1
+        res.append((f.hitcount.copy(), f.histogram.copy(), f.waterfall.copy(), f.spectrum.copy(), f.waterfall_pos))
+        f.close()
+    a, b = res
+    assert np.all(a[0].astype(np.int64).sum(0) == B)
+    assert np.array_equal(a[0], b[0]), "hit counts differ between the shared and the single-stream form"
+    assert np.array_equal(canon_bits(a[1]), canon_bits(b[1])), "histogram"
+    assert np.array_equal(canon_bits(a[2]), canon_bits(b[2])), "waterfall"
+    assert np.array_equal(canon_bits(a[3]), canon_bits(b[3])), "spectrum"
+    assert a[4] == b[4]
+
+
 def test_buffers_without_hitcount_view(amd, torch_cuda, oracle_built, monkeypatch):
     """fosphor_amd_get_buffers_nohc: the pointers / ring position / scale a front end polls per frame, without the hit-count view
     (no export kernel, no wait).  The view made afterwards is still that of the last batch -- also with the single-stream
