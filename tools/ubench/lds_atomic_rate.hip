@@ -7,6 +7,7 @@
 //   layout 3  as 1 with ds_add_rtn (returning atomics)
 //   layout 4  [bin][64] with 16-bit halves of two SPECTRA packed: one ds_add_u32 counts bin b for spectrum t (low) ... not possible (different bins) -- skipped
 //   layout 5  plain ds_write_b32 in the place of the atomic, layout 1 addresses (the LDS pipe's store rate)
+// (addresses are fixed per lane and computed outside the loop: an earlier form hashed them inside it and timed the hash)
 // hipcc --offload-arch=gfx950 -O3 lds_atomic_rate.hip -o lds_atomic_rate && ./lds_atomic_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,16 +24,21 @@ __global__ __launch_bounds__(64 * NW) void k(unsigned *out, int iters, int nb)
 	const unsigned col = (W == 32) ? (lane & 31) : lane;
 	const unsigned inc = (LAYOUT == 0 && (lane & 32)) ? 0x10000u : 1u;
 	unsigned acc = 0;
+	/* eight fixed pseudo-random (bin, column) addresses per lane, computed outside the timed loop: the loop is the LDS operations only */
+	unsigned *ad[8];
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		s = s * 1664525u + 1013904223u;
+		ad[u] = &h[((s >> 16) & (unsigned)(nb - 1)) * W + col];
+	}
 	const long long t0 = clock64();
 	if (LAYOUT != 2 || lane < 32) {
 		for (int it = 0; it < iters; it++) {
 #pragma unroll
 			for (int u = 0; u < 8; u++) {
-				s = s * 1664525u + 1013904223u;
-				const unsigned b = (s >> 16) & (unsigned)(nb - 1);
-				if (LAYOUT == 3) acc += atomicAdd(&h[b * W + col], inc);
-				else if (LAYOUT == 5) h[b * W + col] = s;
-				else atomicAdd(&h[b * W + col], inc);
+				if (LAYOUT == 3) acc += atomicAdd(ad[u], inc);
+				else if (LAYOUT == 5) *(volatile unsigned *)ad[u] = inc;
+				else atomicAdd(ad[u], inc);
 			}
 		}
 	}
