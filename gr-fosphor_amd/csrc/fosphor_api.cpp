@@ -107,8 +107,6 @@ struct fosphor
 	hipEvent_t ev_k2_done[2];		/* K2 wrote hit-count set h */
 	hipEvent_t ev_h_free[2];		/* K3 finished reading hit-count set h */
 	hipEvent_t ev_k3_done;			/* orders K3s that are issued on different streams */
-	hipEvent_t ev_k1h_gate;			/* N = 65536, fused FFT kernel: the previous piece's merge kernel has finished */
-	int       k1h_gate_set;
 	hipStream_t last_k3_stream;
 	hipStream_t k2_stream_last;		/* stream of the most recent count kernel */
 	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
@@ -331,7 +329,6 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_h_free[i]) (void)hipEventDestroy(self->ev_h_free[i]);
 	}
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
-	if (self->ev_k1h_gate) (void)hipEventDestroy(self->ev_k1h_gate);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
 	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
@@ -510,7 +507,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipEventCreateWithFlags(&self->ev_k3_done, dep_event_flags()), "create event");
-	HIP_TRY(hipEventCreateWithFlags(&self->ev_k1h_gate, dep_event_flags()), "create event");
 	if (getenv("FOSPHOR_AMD_K1_TIMING")) {
 		HIP_TRY(hipMalloc((void **)&self->d_dbg, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "alloc timing buffer");
 		HIP_TRY(hipMemset(self->d_dbg, 0, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "clear timing buffer");
@@ -518,11 +514,12 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	{
 		const char *e = getenv("FOSPHOR_AMD_OVERLAP");
 		self->overlap = !(e && *e == '0');
-		/* The fused 65536-point kernel fills every CU: FFT -> count -> scan -> merge run one after the other anyway, and on
-		 * ONE stream the four boundaries cost 4-5 us each instead of 11-14 us of cross-stream event hand-off
-		 * (measured: 134-136 -> 142-144 GSamples/s).  FOSPHOR_AMD_OVERLAP=1 keeps the streams. */
-		if (self->log2n == 16 && self->k1h_fused && !(e && *e == '1'))
-			self->overlap = 0;
+		/* The fused 65536-point kernel fills every CU.  Rounds 2-3 therefore ran FFT -> count -> scan -> merge one after the other on
+		 * ONE stream (then 134-136 -> 142-144 GSamples/s: the radix-8 kernel of 16 waves and 134 KiB of LDS crawled when count / merge
+		 * work-groups reached the CUs first).  The radix-16 kernel of round 4 (8 waves) does not: with the streams, count on the
+		 * second and merge on the third, the tail of frame f runs in the gaps of frame f + 1's FFT kernel -- its ramp-up, and the
+		 * CUs its clusters leave as the tiles run out: 215.3 -> 229.5 GSamples/s (four interleaved runs each; two streams 224.5;
+		 * with the FFT kernel made to wait for the previous merge 199.7).  FOSPHOR_AMD_OVERLAP=0: one stream. */
 		/* N = 8192: the FFT kernel owns every CU's LDS and registers, so count and merge cannot run beside it either way; on one
 		 * stream the kernel boundaries are cheaper than cross-stream events (measured 286.6 / 287.8 / 287.1 against 286.1 / 284.7 /
 		 * 283.5 GSamples/s), and K1's busy time is no longer stretched by launches waiting for each other (0.363 vs 0.29-0.345). */
@@ -532,7 +529,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		e = getenv("FOSPHOR_AMD_K1");
 		self->k1_variant = (e && *e == '2') ? 2 : 1;
 		e = getenv("FOSPHOR_AMD_PIPE3");
-		self->pipe3 = (e && *e == '1');
+		self->pipe3 = e ? (*e == '1') : (self->log2n == 16);	/* (N = 65536: merge on its own stream, above) */
 		e = getenv("FOSPHOR_AMD_ALT");
 		self->alt = !(e && *e == '0');
 		e = getenv("FOSPHOR_AMD_SETS");
@@ -1123,15 +1120,6 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		self->d_partial = self->d_partial_pp[set];
 		if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
 			HIP_TRY(hipStreamWaitEvent(ks, self->ev_set_free[set], 0), "wait for intermediate set");
-		if (self->overlap && self->log2n == 16 && self->k1h_fused && self->k1h_gate_set) {
-			/* The fused FFT kernel fills every CU's LDS for its whole run.  Count / merge kernels that reach the CUs
-			 * first keep its work-groups out (they need a nearly empty CU) while it already spins for its clusters,
-			 * and both crawl (measured 445 us for the FFT kernel instead of 350); a merge kernel held to 64 registers
-			 * so that it fits beside the FFT kernel's waves costs the FFT kernel as much as it hides (470-500 us).
-			 * The FFT kernel therefore starts when the previous piece's merge has finished. */
-			HIP_TRY(hipStreamWaitEvent(ks, self->ev_k1h_gate, 0), "FFT waits for the previous merge kernel");
-		}
-
 		wf_first = wf_first_global - t0;
 		if (wf_first < 0) wf_first = 0;
 		stores_rows = wf_first < sub_total;
@@ -1178,10 +1166,6 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		}
 		if (!(dbg_skip & 4) && run_merge(self, nb, batch, 0, st3, 1, hset))
 			return -EIO;
-		if (self->overlap && self->log2n == 16 && self->k1h_fused) {
-			HIP_TRY(hipEventRecord(self->ev_k1h_gate, st3), "record merge done");
-			self->k1h_gate_set = 1;
-		}
 		if (three) {
 			HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
 			self->hset_used[hset] = 1;
