@@ -107,6 +107,8 @@ struct fosphor
 	hipEvent_t ev_k2_done[2];		/* K2 wrote hit-count set h */
 	hipEvent_t ev_h_free[2];		/* K3 finished reading hit-count set h */
 	hipEvent_t ev_k3_done;			/* orders K3s that are issued on different streams */
+	hipEvent_t ev_tail;			/* N = 8192: behind the merge kernel of the last launch (is there a tail to share the chip with?) */
+	int       tail_set;
 	hipStream_t last_k3_stream;
 	hipStream_t k2_stream_last;		/* stream of the most recent count kernel */
 	hipEvent_t ev_k1_done[kSets];		/* K1 wrote set pp */
@@ -329,6 +331,7 @@ extern "C" void fosphor_release(struct fosphor *self)
 		if (self->ev_h_free[i]) (void)hipEventDestroy(self->ev_h_free[i]);
 	}
 	if (self->ev_k3_done) (void)hipEventDestroy(self->ev_k3_done);
+	if (self->ev_tail) (void)hipEventDestroy(self->ev_tail);
 	(void)hipFree(self->d_hc); (void)hipFree(self->d_hc_export); (void)hipFree(self->d_slab16);
 	(void)hipFree(self->d_rowmask); (void)hipFree(self->d_hot); (void)hipFree(self->d_rowlist);
 	(void)hipFree(self->d_live_sum); (void)hipFree(self->d_vmax);
@@ -507,6 +510,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		HIP_TRY(hipEventCreateWithFlags(&self->ev_h_free[i], dep_event_flags()), "create event");
 	}
 	HIP_TRY(hipEventCreateWithFlags(&self->ev_k3_done, dep_event_flags()), "create event");
+	HIP_TRY(hipEventCreateWithFlags(&self->ev_tail, dep_event_flags()), "create event");
 	if (getenv("FOSPHOR_AMD_K1_TIMING")) {
 		HIP_TRY(hipMalloc((void **)&self->d_dbg, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "alloc timing buffer");
 		HIP_TRY(hipMemset(self->d_dbg, 0, sizeof(long long) * 8 * 4 * kK1MaxBlocks), "clear timing buffer");
@@ -832,6 +836,10 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	{
 		static const bool share = [] { const char *e = getenv("FOSPHOR_AMD_K1W_SHARE"); return !(e && *e == '0'); }();
 		k1->cus = (self->log2n == 13 && self->overlap && share && tile > 0 && (total / tile) % kK1wShareCus == 0) ? kK1wShareCus : 0;
+		/* ... when there is a tail to share with: the count / merge kernels of the launch before this one are still queued or running
+		 * (calls issued back to back).  A launch that finds the chip idle takes all of it. */
+		if (k1->cus && !(self->tail_set && hipEventQuery(self->ev_tail) == hipErrorNotReady))
+			k1->cus = 0;
 	}
 	if (k1->variant == 1 && (k1->hop & 1))
 		k1->variant = 2;		/* 16-byte IQ loads of variant 1 need an even hop */
@@ -1166,6 +1174,10 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		}
 		if (!(dbg_skip & 4) && run_merge(self, nb, batch, 0, st3, 1, hset))
 			return -EIO;
+		if (self->overlap && self->log2n == 13) {
+			HIP_TRY(hipEventRecord(self->ev_tail, st3), "record tail");
+			self->tail_set = 1;
+		}
 		if (three) {
 			HIP_TRY(hipEventRecord(self->ev_h_free[hset], st3), "record hit-count set free");
 			self->hset_used[hset] = 1;
