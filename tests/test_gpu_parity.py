@@ -486,14 +486,18 @@ def test_c3_full_batch_properties(amd, torch_cuda, oracle_built):
     f.close(); f2.close()
 
 
-def test_c3_space_sharing_is_bit_identical(amd, torch_cuda):
+@pytest.mark.parametrize("over,F,sub_log2", [(2, 14, None), (4, 28, "27")])
+def test_c3_space_sharing_is_bit_identical(amd, torch_cuda, monkeypatch, over, F, sub_log2):
     """N = 8192, space sharing: a call whose tiles are a multiple of 224 -- here 14 batches of 1024
-    spectra = 448 tiles of 32 -- runs its FFT kernel on 224 work-groups and the count / merge kernels of the PREVIOUS call on
+    spectra = 448 tiles of 32 -- runs its FFT kernel on 224 work-groups and the count / merge kernels of the PREVIOUS launch on
     the CUs it leaves free.  Two such calls back to back (the second call's FFT kernel beside the first call's count and merge)
     must leave exactly the state of the single-stream form (fosphor_amd_set_overlap(0): 256 work-groups, one kernel at a
-    time): same kernels, same order per cell, so every buffer bit for bit; and every column's counts sum to the batch."""
+    time): same kernels, same order per cell, so every buffer bit for bit; and every column's counts sum to the batch.
+    Second case: 28 batches per call cut into two pieces of 14 (sub-launches of 128 Mi samples), 75 % overlap."""
     torch = torch_cuda
-    n, nb, over, B, F = 8192, 512, 2, 1024, 14
+    if sub_log2:
+        monkeypatch.setenv("FOSPHOR_AMD_SUB_LOG2", sub_log2)
+    n, nb, B = 8192, 512, 1024
     hop = n // over
     xs = [add_tone(gaussian_iq((F * B - 1) * hop + n, 4242 + k), 0.05, 0.0313 + 0.01 * k) for k in range(2)]
     ds = [torch.from_numpy(x).cuda() for x in xs]
