@@ -67,7 +67,10 @@ int fosphor_amd_process_device(struct fosphor *self, const void *d_samples,
  * UNEXPANDED stream; spectrum t of the call is samples [t*N/overlap, t*N/overlap + N), so
  * the buffer must hold (n_batches*batch - 1)*N/overlap + N samples.  overlap must divide N;
  * overlap = 1 is fosphor_amd_process_device.  Results equal processing the stream that
- * overlap_cc(N, overlap) would have produced. */
+ * overlap_cc(N, overlap) would have produced.
+ * (fft_len_log = 13: a call whose spectra count is a multiple of 14 336 = 224 tiles of 64 -- e.g. 14 or 28 batches of 4096 --
+ * issued while the previous call is still being counted lets the FFT kernel run on 224 CUs and the count / merge kernels of the
+ * previous launch on the other 32: +10 % throughput, identical results) */
 int fosphor_amd_process_device_overlap(struct fosphor *self, const void *d_samples,
                                        int n_batches, int batch, int overlap);
 
