@@ -1191,7 +1191,10 @@ void k1w_fft_bin(const K1Params p)
 #define K1W_EPI(M0, M1, tp) do { \
 		const bool _row = ((tp) >= p.wf_first); \
 		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + th; \
-		uint16_t *_bd = bins16 + ((size_t)((tp) >> 1) * N + th) * 2 + ((tp) & 1); \
+		/* index stores: scalar base (+ 4 KiB per two columns of a thread: SALU) + ONE lane offset + immediate -- the flat form cost a \
+		 * 64-bit VALU add (and its hazard nop) per store */ \
+		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2 + ((tp) & 1)); \
+		const uint32_t _bo = 4u * (uint32_t)th; \
 		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
 		_Pragma("unroll") \
 		for (int m = (M0); m < (M1); m++) { \
@@ -1217,7 +1220,10 @@ void k1w_fft_bin(const K1Params p)
 		_Pragma("unroll") \
 		for (int m = (M0); m < (M1); m++) { \
 			const float l2v = _l2[m - (M0)]; \
-			_bd[2 * TH * m] = (uint16_t)_bn[m - (M0)]; \
+			if ((m & 1) == 0) \
+				asm volatile("global_store_short %0, %1, %2" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_bdu + 4096 * (m >> 1)) : "memory"); \
+			else \
+				asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_bdu + 4096 * (m >> 1)) : "memory"); \
 			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
 			vmax[m] = max_f32(vmax[m], l2v); \
 			if (_row) _wf[TH * m] = l2v * F_HALF_LOG10_2; \
