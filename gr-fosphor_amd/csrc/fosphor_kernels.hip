@@ -1226,7 +1226,12 @@ void k1w_fft_bin(const K1Params p)
 				asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_bdu + 4096 * (m >> 1)) : "memory"); \
 			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
 			vmax[m] = max_f32(vmax[m], l2v); \
-			if (_row) _wf[TH * m] = l2v * F_HALF_LOG10_2; \
+		} \
+		if (_row) {		/* uniform, rare (the last wf_rows spectra of a call): one branch per piece instead of one per sample; the row \
+					 * values are recomputed from the log-powers, which the live / max updates above kept alive anyway */ \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) \
+				_wf[TH * m] = _l2[m - (M0)] * F_HALF_LOG10_2; \
 		} \
 	} while (0)
 
