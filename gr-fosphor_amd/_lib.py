@@ -113,6 +113,7 @@ SIGNATURES = {
     "fosphor_amd_stream2": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_upload_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_tune_placement": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "fosphor_amd_plan_piece_batches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]),
     "fosphor_amd_version": (C.c_char_p, []),
     # include/fosphor_amd_axis.h
     "fosphor_amd_freq_axis_build": (None, [C.c_void_p, C.c_double, C.c_double, C.c_int]),

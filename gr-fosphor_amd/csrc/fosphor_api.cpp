@@ -865,6 +865,27 @@ static int use_rowmask(const struct fosphor *self)
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
+/* Batches per sub-launch ("piece") of a device-resident call of n_batches batches: about sub_samples samples each, pieces of equal
+ * size.  N = 8192 with the streams on: pieces of whole `unit`s of batches where the call allows it, so that every piece's tiles are a
+ * multiple of kK1wShareCus and the FFT launch can leave CUs to the count / merge kernels (tiles are 64 spectra or the batch:
+ * pick_tile).  Pure host arithmetic, exported for the CPU test suite (include/fosphor_amd.h). */
+extern "C" int fosphor_amd_plan_piece_batches(int log2n, int overlap, int n_batches, int batch, long long sub_samples)
+{
+	if (n_batches < 1 || batch < 1 || log2n < 1 || log2n > 30 || sub_samples < 1)
+		return -EINVAL;
+	const long long per_batch = (long long)batch << log2n;
+	const int cap = (int)(sub_samples / per_batch < 1 ? 1 : (sub_samples / per_batch > n_batches ? n_batches : sub_samples / per_batch));
+	const int n_sub = (n_batches + cap - 1) / cap;
+	int sub_b = (n_batches + n_sub - 1) / n_sub;
+	if (log2n == 13 && overlap && n_sub > 1) {
+		const int tpb = batch >= 64 ? batch / 64 : 1;
+		const int unit = kK1wShareCus / gcd_int(kK1wShareCus, tpb);
+		if (n_batches % unit == 0 && cap >= unit)
+			sub_b = cap / unit * unit;
+	}
+	return sub_b;
+}
+
 /* K2 (+K2b) for n_batches batches of `batch` spectra whose bin indices / tile partials are in
  * d_bins / d_partial; results land in slot `slot0`.. of hc / live_sum / vmax. */
 static int run_count(struct fosphor *self, int n_batches, int batch, int tile, int slot0,
@@ -1083,20 +1104,8 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	 *   K2 (j)   on stream2 once K1 (j) has finished; K3 (j) follows it there, so the persistent state sees the
 	 *            batches in order.
 	 * The intermediates rotate among kSets sets: K1 may reuse a set once the K2 that read it has finished. */
-	sub_b = (int)(self->sub_samples / ((long long)batch * self->n));
-	if (sub_b < 1) sub_b = 1;
-	if (sub_b > n_batches) sub_b = n_batches;
+	sub_b = fosphor_amd_plan_piece_batches(self->log2n, self->overlap, n_batches, batch, self->sub_samples);
 	n_sub = (n_batches + sub_b - 1) / sub_b;
-	sub_b = (n_batches + n_sub - 1) / n_sub;
-	if (self->log2n == 13 && self->overlap && n_sub > 1) {
-		/* space sharing needs every piece's tiles to be a multiple of kK1wShareCus: pieces of whole `unit`s of batches where the
-		 * call allows it (tiles are 64 spectra or the batch: pick_tile) */
-		const int tpb = batch >= 64 ? batch / 64 : 1;
-		const int unit = kK1wShareCus / gcd_int(kK1wShareCus, tpb);
-		const int cap = (int)(self->sub_samples / ((long long)batch * self->n));
-		if (n_batches % unit == 0 && cap >= unit)
-			sub_b = cap / unit * unit;
-	}
 	use_alt = self->overlap && self->alt && device_call && (n_sub > 1 || self->relaxed);
 	if (self->log2n == 16 && self->k1h_fused)
 		use_alt = 0;		/* one fused FFT kernel at a time: its clusters own the counters and the intermediate */

@@ -265,6 +265,12 @@ void *fosphor_amd_upload_stream(struct fosphor *self);
 int fosphor_amd_tune_placement(struct fosphor *self, const void *d_samples, int n_batches, int batch, int max_tries,
                                float *us_before, float *us_after);
 
+/* Host-logic test hook (no device needed): batches per sub-launch of a fosphor_amd_process_device* call of n_batches batches of
+ * `batch` spectra at FFT length 2^fft_len_log, for a sub-launch size of sub_samples samples (64 Mi by default, 1 Gi at
+ * fft_len_log = 13) -- at fft_len_log = 13 with the streams on, whole multiples of the unit that lets a piece share the chip
+ * (224 tiles of 64 spectra).  -EINVAL for nonsense. */
+int fosphor_amd_plan_piece_batches(int fft_len_log, int overlap, int n_batches, int batch, long long sub_samples);
+
 /* Library identification: "fosphor_amd <version> gfx950". */
 const char *fosphor_amd_version(void);
 

@@ -45,6 +45,27 @@ def test_library_exports_every_declared_symbol(amd):
     assert not unbound, "exported but unbound in _lib.py: %s" % unbound
 
 
+def test_piece_planner_host_logic(amd):
+    """fosphor_amd_plan_piece_batches: how a device-resident call is cut into sub-launches (pure host arithmetic).  Pieces are
+    about sub_samples samples and equal; at fft_len_log = 13 with the streams on they are whole multiples of the unit that makes
+    a piece's tiles (64 spectra each) a multiple of 224, so that the FFT launch can leave CUs to the count / merge kernels
+     -- when the call's batch count allows it."""
+    plan = amd.load().fosphor_amd_plan_piece_batches
+    assert plan(10, 1, 256, 1024, 1 << 26) == 64		# the C2 bench call: 4 pieces of 64 reference batches
+    assert plan(10, 1, 100, 1024, 1 << 26) == 50		# equal pieces, not 64 + 36
+    assert plan(10, 1, 3, 1024, 1 << 26) == 3
+    assert plan(13, 1, 28, 4096, 1 << 30) == 28			# the C3 bench call: one piece (1792 tiles = 8 x 224)
+    assert plan(13, 1, 56, 4096, 1 << 30) == 28			# cap 32 -> whole units of 7 batches
+    assert plan(13, 1, 64, 4096, 1 << 30) == 32			# 64 is no multiple of 7: plain equal pieces
+    assert plan(13, 0, 56, 4096, 1 << 30) == 28			# one stream: equal pieces (28 + 28), no unit logic needed
+    assert plan(13, 1, 28, 1024, 1 << 27) == 14			# 1024-spectrum batches are 16 tiles: unit 14, cap 16
+    assert plan(13, 1, 42, 1024, 1 << 27) == 14
+    assert plan(16, 1, 8, 1024, 1 << 26) == 1			# a 65536-point frame is a piece of its own
+    assert plan(13, 1, 4, 4096, 1 << 20) == 1			# a piece is never less than a batch
+    for bad in [(0, 1, 4, 64, 1 << 26), (10, 1, 0, 64, 1 << 26), (10, 1, 4, 0, 1 << 26), (10, 1, 4, 64, 0)]:
+        assert plan(*bad) == -22				# -EINVAL
+
+
 def test_struct_layouts_match_reference_abi(amd):
     """struct fosphor_render / fosphor_channel layout (fosphor.h:42-90 of the reference):
     10 user words, 8 channels of 3 words, then 11 private words."""
