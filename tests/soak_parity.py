@@ -2,7 +2,7 @@
 """One-off large-sample parity check (not part of the test suite: ~10^9 samples): hit counts of every batch
 against the oracle, bit for bit, for several seeds / signal mixes / power ranges, at 128 and 256 bins.
 
-    python3 tests/soak_parity.py [n_seeds [c2|c3|c5|pipe]]          (kept under tests/: it uses the oracle as the checker)
+    python3 tests/soak_parity.py [n_seeds [c2|c3|c5|pipe|share]]          (kept under tests/: it uses the oracle as the checker)
 """
 import os
 import sys
@@ -120,7 +120,47 @@ def pipe(n_calls):
     return 1 if (bad_cells or bad_state) else 0
 
 
+def share(n_pairs):
+    """N = 8192 in the space-sharing form: calls of 14 batches of 1024 spectra (448 tiles: the FFT launch
+    runs on 224 CUs when the previous call's count / merge kernels are still pending), issued in PAIRS without looking at the
+    results in between; after each pair the last batch's counts bit-exact and the state in tolerance against the oracle,
+    which has seen the same 28 batches one by one."""
+    build_oracle(ref=False)
+    threads = min(os.cpu_count() or 1, 64)
+    n, F, B = 8192, 14, 1024
+    f = gr_fosphor_amd.Fosphor(fft_len_log=13, n_bins=512, max_spectra=F * B, max_batches=F)
+    o = Oracle(fft_len_log=13, n_bins=512)
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    bad_cells = bad_state = 0
+    t0 = time.time()
+    for pair in range(n_pairs):
+        ds = []
+        for call in range(2):
+            d = torch.empty((F * B * n, 2), dtype=torch.float32, device="cuda").normal_(0.0, [0.05, 0.4, 0.004][(2 * pair + call) % 3], generator=g)
+            if call:
+                t = torch.arange(F * B * n, device="cuda", dtype=torch.float32)
+                d[:, 0] += 0.1 * torch.cos(0.21 * (pair + 1) * t); d[:, 1] += 0.1 * torch.sin(0.21 * (pair + 1) * t)
+            ds.append(d)
+        torch.cuda.synchronize()
+        for d in ds:						# back to back: the second call's FFT launch shares the chip with the first call's tail
+            assert f.process_device(d, F, B) == 0
+        for d in ds:
+            x = d.cpu().numpy()
+            for k in range(F):
+                assert o.process(x[k * B * n:(k + 1) * B * n], strict=False, nthreads=threads) == 0
+        bad = int((f.hitcount != o.hitcount.T).sum())
+        hist_bad = int((np.abs(f.histogram - o.histogram) > 2e-6 + 1e-4 * np.abs(o.histogram)).sum())
+        live_bad = int((~np.isclose(f.spectrum[..., 1], o.spectrum[..., 1], rtol=1e-4, atol=1e-6)).sum())
+        wf_bad = int((~np.isclose(f.waterfall, o.waterfall, rtol=1e-4, atol=1e-6)).sum())
+        bad_cells += bad; bad_state += hist_bad + live_bad + wf_bad
+        print("pair %d: %d count cells, %d histogram cells, %d spectrum values, %d waterfall texels differ" % (pair, bad, hist_bad, live_bad, wf_bad), flush=True)
+    print("N=8192 shared: %d samples in %d pairs of calls of %d batches, %d mismatching hit-count cells, %d state values out of tolerance, %.0f s"
+          % (n_pairs * 2 * F * B * n, n_pairs, F, bad_cells, bad_state, time.time() - t0))
+    f.close()
+    return 1 if (bad_cells or bad_state) else 0
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     which = sys.argv[2] if len(sys.argv) > 2 else "c2"
-    sys.exit(main(n) if which == "c2" else pipe(n) if which == "pipe" else big(n, 13, False) if which == "c3" else big(n, 16, True))
+    sys.exit(main(n) if which == "c2" else pipe(n) if which == "pipe" else share(n) if which == "share" else big(n, 13, False) if which == "c3" else big(n, 16, True))
