@@ -3,7 +3,10 @@
 
 Contract (one JSON line on rank 0):
     python bench.py --gpus N --steps K --warmup W
-    N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    N > 1 without a launcher (WORLD_SIZE unset): this process starts
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+    as a CHILD, before anything here has touched the GPU, relays rank 0's JSON line and exits with the child's code.
+    Under a launcher (WORLD_SIZE set) it is one rank of N.
 
 A STEP is ONE CALL of the library's device-resident entry point with --batches-per-step (256)
 reference batches of BASELINE config C2 -- 1024 spectra x 1024 points each, 1024x256 histogram +
@@ -22,11 +25,14 @@ settled: the first milliseconds of a run are 10-30 % slower.
          time-sharded over the ranks; hit counts / live sums / max are all-reduced over RCCL once per
          frame and every rank applies the same state update; per-GPU work is the same at
          every N (weak scaling, BASELINE configs[3] "C4").  FOSPHOR_AMD_FORCE_EXCHANGE=1 runs the
-         collectives on a single rank.
+         collectives on a single rank.  `--mode frame --batches-per-step 1` is SURVEY 8e's "K = 1, honest
+         worst case": one exchange per 1024-spectrum launch per GPU instead of one per display frame.
 
 Other BASELINE configurations: --config C3 (8192-pt FFT, 50 % overlap fused into the read, batch
 4096, 512 bins) and --config C5 (65536-pt FFT, fp16 IQ, 512 bins, the per-GPU share of a sharded
-frame) emit the same JSON shape with their own workload string and roofline convention.
+frame) emit the same JSON shape with their own workload string and roofline convention.  The default
+run (C2, one GPU) ALSO measures C3 and C5 for 20 steps each, in the same process, after the headline,
+and reports them inside the one JSON line as `other_configs` (--no-other-configs skips them).
 
 roofline: the dominant kernel is K1 (fft_bin), bound by the HBM read of the IQ stream (8 B per
 sample, 4 B for fp16 IQ).  K1s of consecutive sub-launches run on alternating streams and overlap
@@ -83,96 +89,179 @@ def parse():
     ap.add_argument("--no-placement-tuning", action="store_true",
                     help="take the allocations as they come (default: fosphor_amd_tune_placement once, untimed, before the pre-conditioning)")
     ap.add_argument("--placement-candidates", type=int, default=1,
-                    help="batch mode: instances (= sets of allocations) tried before the run; the fastest over 48 untimed steps is kept")
+                    help="batch mode, NOT for headline runs: instances (= sets of allocations) tried before the run; the fastest over 48 untimed steps is kept")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the informational K2/K3 and isolated-K1 passes")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default C2 run on one GPU: do not measure C3 / C5 afterwards (other_configs in the JSON line)")
+    ap.add_argument("--other-steps", type=int, default=20, help="steps per configuration of the other_configs pass")
     ap.add_argument("--strict-ordering", action="store_true", help="keep stream ordering between calls (default: relaxed, "
                     "the input ring is never rewritten)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start one as a child (no GPU call has been made in this process)
+# ---------------------------------------------------------------------------------------------------
+
+def launcher_command(n_gpus, argv, port):
+    """The command `bench.py --gpus N` starts when no launcher did (pure function: tests/test_boundary_cpu.py)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """Child process, output relayed: rank 0's JSON line goes to our stdout (once), everything else to stderr; our exit code is the
+    child's.  Nothing here imports torch or touches the GPU -- a process that has initialised the GPU must never be replaced."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")		# dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_command(args.gpus, sys.argv[1:], port)
+    sys.stderr.write("bench.py: no launcher (WORLD_SIZE unset), starting: %s\n" % " ".join(cmd))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line_seen = False
+    for line in proc.stdout:
+        st = line.strip()
+        if not line_seen and st.startswith("{") and '"metric"' in st:
+            print(st, flush=True)
+            line_seen = True
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and not line_seen:
+        sys.stderr.write("bench.py: the launched ranks exited 0 without a JSON line\n")
+        rc = 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------
+
+def numa_cpu_groups(allowed):
+    """[[cpu, ...] per NUMA node] restricted to the CPUs this process may run on (one group when the topology cannot be read)."""
+    groups = []
+    try:
+        base = "/sys/devices/system/node"
+        for d in sorted((x for x in os.listdir(base) if x.startswith("node") and x[4:].isdigit()), key=lambda x: int(x[4:])):
+            cpus = []
+            for part in open(os.path.join(base, d, "cpulist")).read().strip().split(","):
+                if not part:
+                    continue
+                a, _, b = part.partition("-")
+                cpus.extend(range(int(a), int(b or a) + 1))
+            cpus = [c for c in cpus if c in allowed]
+            if cpus:
+                groups.append(cpus)
+    except Exception:
+        groups = []
+    if not groups:
+        groups = [sorted(allowed)]
+    return groups
+
+
 def cpu_baseline(bins, seconds):
-    """Oracle (CPU restatement of the reference kernels) on ALL online host cores, bounded sample.
+    """Oracle (CPU restatement of the reference kernels), bounded sample, the best the host does.
 
     One oracle instance parallelises a batch over at most 64 threads (its display stage has 64 column groups of 16,
-    cl.c:945-950), so a host with more cores runs cores // 64 independent instances side by side, each on its own
-    stream of batches -- the way several sink blocks would share the host.  cores = threads actually used."""
+    cl.c:945-950).  Two legs, half the time budget each:
+      all-core    one instance per 64 CPUs of every NUMA node, each PINNED to its CPUs (sched_setaffinity in the worker thread,
+                  inherited by the oracle's pthreads) with its input and its state first-touched from there -- the way several
+                  sink blocks would share the host;
+      one-instance  a single instance of 64 threads pinned to (the first 64 CPUs of) one node.
+    value = the faster leg; cores = the threads that leg actually used.  The instrument this stands beside: main.c:141-155."""
     import threading
+    import numpy as np
     from oracle_lib import Oracle, build_oracle, gaussian_iq
     build_oracle(ref=False)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    per = min(cores, 64)
-    inst = max(1, cores // 64)
-    x = gaussian_iq(1024 * 1024, 7)
-    oracles = [Oracle(n_bins=bins) for _ in range(inst)]
-    for o in oracles:
-        o.process(x, nthreads=per)		# warm-up, page in
-    counts = [0] * inst
-    t0 = time.perf_counter()
+    allowed = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    nodes = numa_cpu_groups(allowed)
+    x0 = gaussian_iq(1024 * 1024, 7)
 
-    def work(i):				# (ctypes releases the GIL for the duration of the C call)
-        while time.perf_counter() - t0 < seconds and counts[i] < 4096:
-            oracles[i].process(x, nthreads=per)
-            counts[i] += 1
+    def leg(groups, budget):
+        counts = [0] * len(groups)
+        ready = threading.Barrier(len(groups) + 1)
+        t_start = [0.0]
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(inst)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    el = time.perf_counter() - t0
-    n = sum(counts)
-    return {"value": n * 1024 * 1024 / el / 1e6, "unit": "MSamples/s", "cores": per * inst, "kind": "port",
-            "cores_online": cores,
+        def work(i):				# (ctypes releases the GIL for the duration of the C call)
+            try:
+                os.sched_setaffinity(0, groups[i])		# pid 0 = the calling thread; the oracle's pthreads inherit it
+            except Exception:
+                pass
+            x = np.array(x0, copy=True)			# first touch on this node
+            o = Oracle(n_bins=bins)
+            o.process(x, nthreads=len(groups[i]))		# warm-up: pages in the instance's state, here
+            ready.wait()
+            while time.perf_counter() - t_start[0] < budget and counts[i] < 4096:
+                o.process(x, nthreads=len(groups[i]))
+                counts[i] += 1
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(len(groups))]
+        for t in ths:
+            t.start()
+        t_start[0] = time.perf_counter() + 1e9		# (workers do not start timing before the barrier releases)
+        ready.wait()
+        t_start[0] = time.perf_counter()
+        for t in ths:
+            t.join()
+        el = time.perf_counter() - t_start[0]
+        n = sum(counts)
+        return {"value": n * 1024 * 1024 / el / 1e6, "batches": n, "seconds": el, "instances": len(groups),
+                "threads": sum(len(g) for g in groups)}
+
+    all_groups = [node[i:i + 64] for node in nodes for i in range(0, len(node), 64)]
+    flat = [c for node in nodes for c in node]
+    one_group = [nodes[0][:64] if len(nodes[0]) >= 64 else flat[:64]]
+    two = len(all_groups) > 1 or len(all_groups[0]) != len(one_group[0])
+    legs = {"all_core": leg(all_groups, seconds / 2 if two else seconds)}
+    if two:
+        legs["one_instance"] = leg(one_group, seconds / 2)
+    best = max(legs, key=lambda k: legs[k]["value"])
+    b = legs[best]
+    return {"value": b["value"], "unit": "MSamples/s", "cores": b["threads"], "kind": "port",
+            "cores_online": len(allowed), "numa_nodes": len(nodes), "leg": best,
+            "legs": {k: {"value": v["value"], "cores": v["threads"], "instances": v["instances"]} for k, v in legs.items()},
             "sample": "%d batches of 1024 x 1024-pt spectra (%.1f s), oracle C restatement of fft.cl+display.cl, "
-                      "%d instance(s) x %d threads = %d of %d online host cores; the reference's own OpenCL path could not "
-                      "be run: no OpenCL CPU runtime (POCL) exists in this image and reference sources do not travel to "
-                      "the GPU box" % (n, el, inst, per, per * inst, cores)}
+                      "%d instance(s) pinned to their NUMA node's CPUs, %d threads of %d online host cores (%s); the reference's own "
+                      "OpenCL path could not be run: no OpenCL CPU runtime (POCL) exists in this image and reference sources do "
+                      "not travel to the GPU box" % (b["batches"], b["seconds"], b["instances"], b["threads"], len(allowed),
+                                                     "; ".join("%s %.0f MS/s on %d" % (k, v["value"], v["threads"]) for k, v in legs.items()))}
 
 
-def main():
-    args = parse()
-    # The library's two FFT streams must not share a hardware queue with each other or with RCCL's streams
-    # (HIP maps streams onto 4 queues by default; DESIGN.md section 5 "Hardware queues"): neutral at N=1 (measured).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    import torch
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------
+# one configuration
+# ---------------------------------------------------------------------------------------------------
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # (FOSPHOR_BENCH_BACKEND=gloo: test hook -- several ranks sharing ONE GPU, which RCCL refuses; tests/test_gpu_dist.py)
-        backend = os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-
-    from _pkg import gr_fosphor_amd
+def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
+    """Measures configuration `name`; returns the JSON object (rank 0) or None (other ranks).  light: the other_configs pass --
+    no placement tuning, no extra passes, no twin, no CPU leg (those describe the headline)."""
+    torch, dist, gr_fosphor_amd = ctx["torch"], ctx["dist"], ctx["pkg"]
+    world, rank = ctx["world"], ctx["rank"]
     from gr_fosphor_amd.dist import ShardedFosphor
 
-    cfg = CONFIGS[args.config]
+    cfg = CONFIGS[name]
     n_fft = 1 << cfg["log2n"]
-    bins = args.bins or cfg["bins"]
+    bins = (args.bins if not light else 0) or cfg["bins"]
     spb = cfg["spb"]
     over = cfg["over"]
     bytes_per_sample = 4 if cfg["fp16"] else 8	# SURVEY 8d: algorithmic read per FFT'd sample (materialised-stream convention)
     mode = args.mode if args.mode != "auto" else ("batch" if world == 1 else "frame")
-    F = args.batches_per_step if args.batches_per_step > 0 else cfg["bps"]
+    if light:
+        mode = "batch"
+    F = batches_per_step if batches_per_step > 0 else (args.batches_per_step if (args.batches_per_step > 0 and not light) else cfg["bps"])
     ring = max(1, args.ring_steps)
     samples_per_batch = spb * n_fft			# FFT'd samples
     hop = n_fft // over
     # unexpanded stream of one step: (F*spb - 1) * hop + n_fft samples (overlap_cc_impl.cc:64-79)
     step_stream = (F * spb - 1) * hop + n_fft if over > 1 else F * samples_per_batch
+    extra = not (args.no_extra_passes or light)
+    precondition = args.precondition if not light else min(args.precondition, 0.25)
 
     # synthetic white complex Gaussian IQ, sigma 0.05 per component (SURVEY 8d), resident in HBM;
     # the ring is larger than the 256 MiB Infinity Cache, so IQ reads come from HBM
@@ -236,17 +325,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n):
+        t_s = time.perf_counter()
+        run_steps(n)
+        sync()
+        return n * F * samples_per_batch / (time.perf_counter() - t_s) / 1e6
+
     f.finish()				# instance boot (table uploads, initial fills: cl.c:981-995) is not a step
     # Placement (untimed, once): on MI355X the FFT kernel's memory traffic runs in one of two states -- 98 or 109 us per 512 MiB of IQ --
     # decided by the allocations involved (the IQ buffer against the instance's intermediate sets).  The library
     # re-allocates its sets until the traffic runs at 6 TB/s (fosphor_amd_tune_placement); if none does, the IQ ring is the unlucky side
-    # and is allocated again (same distribution, the generator's next numbers).
+    # and is allocated again (same distribution, the generator's next numbers).  The rate of the allocations AS THEY CAME is measured
+    # first and reported beside the headline (placement.untuned_value).
     placement = None
-    if cfg["log2n"] == 10 and bins <= 256 and not args.no_placement_tuning and F >= 16:	# (a launch long enough for its time to be bandwidth)
+    if cfg["log2n"] == 10 and bins <= 256 and not args.no_placement_tuning and not light and F >= 16:	# (a launch long enough for its time to be bandwidth)
         sub_t = min(F, 64)
         n_t = sub_t * samples_per_batch
         good_us = (n_t * 9.0 + n_t / 64 * 8.0) / 6.0e12 * 1e6
         placement = {"iq_allocations": 1, "sets_replaced": 0, "twin_us_first": None, "twin_us_final": None, "good_us": good_us}
+        if mode == "batch":
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < min(precondition, 0.3):
+                run_steps(4); sync()
+            placement["untuned_value"] = timed(max(8, min(steps, 40)))	# MSamples/s before any re-allocation (untimed extra pass)
+            state["pos"] = 0
 
         def tune(inst):
             nonlocal iq
@@ -272,11 +374,9 @@ def main():
             # a few candidate instances (each a fresh set of allocations), 48 untimed steps each, the fastest stays.
             def quick_rate():
                 t_w = time.perf_counter()
-                while time.perf_counter() - t_w < min(args.precondition, 0.2):	# (every candidate warmed alike: clocks, first touches)
+                while time.perf_counter() - t_w < min(precondition, 0.2):	# (every candidate warmed alike: clocks, first touches)
                     run_steps(4); sync()
-                t_q = time.perf_counter()
-                run_steps(48); sync()
-                return 48 * F * samples_per_batch / (time.perf_counter() - t_q) / 1e6
+                return timed(48)
             cands.append((quick_rate(), f))
             for c in range(1, args.placement_candidates):
                 f = gr_fosphor_amd.Fosphor(stream=stream, **kw)
@@ -296,30 +396,32 @@ def main():
     # untimed pre-conditioning: the same steps until the clocks have settled
     t0 = time.perf_counter()
     pre_steps = 0
-    while time.perf_counter() - t0 < args.precondition:
+    while time.perf_counter() - t0 < precondition:
         run_steps(4)
         sync()
         pre_steps += 4
     precondition_s = time.perf_counter() - t0
 
-    run_steps(args.warmup)
+    run_steps(warmup)
     sync()
+    share0 = f.share_stats()
     # timed region: hipEvents around K1 only (events around K2/K3 too sit on the critical path of the
     # count/merge stream)
     if not os.environ.get("BENCH_NO_PROFILE"):	# debugging aid: cost of the hipEvents themselves
         f.profile(2)
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(steps)
     t_submit = time.perf_counter() - t0		# host time to queue everything (host-bound if ~ elapsed)
     sync()
     elapsed = time.perf_counter() - t0
     busy = f.kernel_busy()
     ms, launches = f.kernel_times()
+    share1 = f.share_stats()
     xchg_ms, xchg_n = f.exchange_time()		# hipEvents around the ncclGroup on the count/merge stream (native transport)
     exchange_ranks = sf.exchange_ranks() if sf is not None else 1	# ncclCommCount of the library's communicator
 
     ms_all, n_all, iso, twin_ms = [0.0] * 3, [0] * 3, None, None
-    if not args.no_extra_passes:
+    if extra:
         # K2 / K3 durations in the pipeline (informational): a short extra pass with events around
         # every kernel, outside the timed region
         f.profile(1)
@@ -346,20 +448,16 @@ def main():
     # The headline runs with relaxed input ordering (the caller promises to leave the samples alone until finish()); the same
     # steps with the default, strict ordering against the caller's stream are timed beside it, outside the timed region.
     strict_value = None
-    if mode == "batch" and not args.strict_ordering and not args.no_extra_passes:
+    if mode == "batch" and not args.strict_ordering and extra:
         f.set_input_ordering(True)
         run_steps(3)
         sync()
-        n_strict = max(4, min(args.steps, 40))
-        ts = time.perf_counter()
-        run_steps(n_strict)
-        sync()
-        strict_value = n_strict * F * samples_per_batch / (time.perf_counter() - ts) / 1e6
+        strict_value = timed(max(4, min(steps, 40)))
         f.set_input_ordering(False)
 
     # the practical ceiling for K1 on this chip: its memory traffic (same loads, order, prefetch depth, stores)
     # without its arithmetic, measured live on the same buffers
-    if mode == "batch" and args.config == "C2" and not args.no_traffic_twin:
+    if mode == "batch" and name == "C2" and not args.no_traffic_twin and not light:
         try:
             sub = min(F, 64)
             twin_ms = f.traffic_twin(iq[:sub * samples_per_batch], sub, spb, reps=50)
@@ -373,20 +471,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        g = torch.zeros(world, 2, dtype=torch.float64, device="cuda")
-        g[rank, 0], g[rank, 1] = k1_busy_rank, float(exchange_ranks)
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-        k1_busy_ranks = [float(v) for v in g[:, 0].tolist()]
-        xchg_ranks_all = [int(v) for v in g[:, 1].tolist()]
+        gg = torch.zeros(world, 2, dtype=torch.float64, device="cuda")
+        gg[rank, 0], gg[rank, 1] = k1_busy_rank, float(exchange_ranks)
+        dist.all_reduce(gg, op=dist.ReduceOp.SUM)
+        k1_busy_ranks = [float(v) for v in gg[:, 0].tolist()]
+        xchg_ranks_all = [int(v) for v in gg[:, 1].tolist()]
 
-    total_samples = world * args.steps * F * samples_per_batch
+    total_samples = world * steps * F * samples_per_batch
     value = total_samples / elapsed / 1e6
 
+    out = None
     if rank == 0:
         n_k1 = max(1, launches[0])
         k1_ms = ms[0] / n_k1					# plain average of the individual launch durations
         k1_busy = busy[0] / n_k1				# union of the K1 intervals / launches
-        samples_per_launch = args.steps * F * samples_per_batch / n_k1
+        samples_per_launch = steps * F * samples_per_batch / n_k1
         alg_bytes = bytes_per_sample * samples_per_launch
         achieved = alg_bytes / (k1_busy * 1e-3) / 1e9 if k1_busy > 0 else 0.0
         achieved_plain = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
@@ -405,7 +504,7 @@ def main():
             except Exception:
                 continue
             for e in (j if isinstance(j, list) else [j]):
-                if (e.get("config") == args.config and e.get("bins") == bins and
+                if (e.get("config") == name and e.get("bins") == bins and
                         abs(e.get("samples_per_launch", 0) - samples_per_launch) < 1):
                     traffic, traffic_src = e.get("hbm_bytes_per_launch"), os.path.basename(pmc)
                     break
@@ -421,78 +520,88 @@ def main():
             k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"
         sub_b = samples_per_launch / samples_per_batch
         wf_rows = 1024
-        out = {
-            "metric": "complex IQ MSamples/s @%d-pt FFT" % n_fft,
-            "value": value, "unit": "MSamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": cfg["text"] % dict(bins=bins, bps=F, msamp=F * samples_per_batch >> 20,
-                                               mib=F * samples_per_batch * bytes_per_sample >> 20, sub=int(round(sub_b))),
-                "mode": mode, "batches_per_step": F, "spectra_per_batch": spb, "ring_steps": ring,
-                "k1_launches_per_step": n_k1 / max(1, args.steps),
-                "input": "white complex Gaussian sigma=0.05, %s IQ resident in HBM (%d MiB ring, written once)"
-                         % ("fp16" if cfg["fp16"] else "fp32", iq.numel() * iq.element_size() >> 20),
-                "precondition_s": precondition_s, "precondition_steps": pre_steps,
-                "placement": placement,	# allocations re-rolled before the run until the FFT kernel's memory twin ran in its fast state
+        roofline = {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "k1_busy_ms_per_launch": k1_busy, "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
+                    "k1_overlap": (ms[0] / busy[0]) if busy[0] > 0 else None,
+                    "achieved_plain_average": achieved_plain, "frac_plain_average": achieved_plain / HBM_PEAK_GBS,
+                    "accounting": "K1s of consecutive sub-launches run on two streams and overlap at their edges: achieved = "
+                                  "algorithmic bytes of all K1 launches / time with at least one K1 running (union of the "
+                                  "hipEvent intervals); *_plain_average divides by the mean individual duration, which counts "
+                                  "the shared time twice",
+                    "whole_path_frac": value * 1e6 * bytes_per_sample / 1e9 / HBM_PEAK_GBS / max(1, world),
+                    # also against what the part delivers (6.29 TB/s float4 copy, MI355X_MICROARCH.md)
+                    "frac_of_achievable": achieved / ACHIEVABLE_GBS,
+                    "k1_traffic_rate_GBs": (traffic / 1e9 / (k1_busy * 1e-3)) if (traffic and k1_busy > 0) else None,
+                    "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
+                    "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "unique_bytes_per_launch": alg_bytes / over,
+                    "isolated": isolated,
+                    "traffic_twin": None if not twin_ms else {
+                        "ms_per_launch": twin_ms,
+                        "k1_isolated_over_twin": (iso / twin_ms) if iso else None,
+                        "note": "a kernel with K1's loads (same tile order, prefetch depth) and stores but no arithmetic, "
+                                "same buffers: the practical floor the memory system sets for one K1 launch"}}
+        if cfg["log2n"] == 13:
+            # the form the FFT launches of the timed steps took (chosen at submit time from the state of the queue)
+            roofline["fft_launch_form"] = {"shared": share1[0] - share0[0], "full_chip": share1[1] - share0[1], "shared_work_groups": share1[2]}
+        workload = cfg["text"] % dict(bins=bins, bps=F, msamp=F * samples_per_batch >> 20,
+                                      mib=F * samples_per_batch * bytes_per_sample >> 20, sub=int(round(sub_b)))
+        if light:
+            out = {"metric": "complex IQ MSamples/s @%d-pt FFT" % n_fft, "value": value, "unit": "MSamples/s",
+                   "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / steps, "dtype": "f32",
+                   "workload": workload, "batches_per_step": F, "precondition_s": precondition_s,
+                   "input_ordering": "strict" if args.strict_ordering else "relaxed",
+                   "host_submit_fraction": t_submit / elapsed,
+                   "roofline": {k: roofline[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "k1_busy_ms_per_launch",
+                                                         "k1_ms_per_launch", "k1_launches", "whole_path_frac", "algorithmic_bytes_per_launch",
+                                                         "unique_bytes_per_launch") }}
+            if "fft_launch_form" in roofline:
+                out["roofline"]["fft_launch_form"] = roofline["fft_launch_form"]
+        else:
+            out = {
+                "metric": "complex IQ MSamples/s @%d-pt FFT" % n_fft,
+                "value": value, "unit": "MSamples/s",
+                "n_gpus": world, "steps": steps, "warmup": warmup,
+                "ms_per_step": elapsed * 1e3 / steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {
+                    "workload": workload,
+                    "mode": mode, "batches_per_step": F, "spectra_per_batch": spb, "ring_steps": ring,
+                    "k1_launches_per_step": n_k1 / max(1, steps),
+                    "input": "white complex Gaussian sigma=0.05, %s IQ resident in HBM (%d MiB ring, written once)"
+                             % ("fp16" if cfg["fp16"] else "fp32", iq.numel() * iq.element_size() >> 20),
+                    "precondition_s": precondition_s, "precondition_steps": pre_steps,
+                    "placement": placement,	# allocations re-rolled before the run until the FFT kernel's memory twin ran in its fast state
 
-                "waterfall": "dead-store rule: a row that a later spectrum of the same call overwrites is not stored, "
-                             "so a step stores the rows of its last %d of %d spectra (the ring ends in the same state; "
-                             "the reference would store all of them)" % (min(wf_rows, F * spb), F * spb),
-                "input_ordering": "strict" if args.strict_ordering else "relaxed",
-                "strict_ordering_value": strict_value,	# MSamples/s of the same steps with the default (strict) ordering, untimed extra pass
-                "host_submit_fraction": t_submit / elapsed,
-                # multi-GPU self-description: what the exchange actually spanned, as the transport itself reports it
-                "transport": ("none" if (sf is None or not sf.active) else
-                              "native RCCL (library communicator)" if sf.exchange == "rccl" else "torch.distributed (%s)" % dist.get_backend()),
-                "transport_agreement": transport,
-                "exchange_ranks": exchange_ranks,			# ncclCommCount(library communicator) on rank 0 (1 = no exchange)
-                "exchange_ranks_per_rank": xchg_ranks_all,
-                "exchange_ms_per_frame": (xchg_ms / xchg_n) if xchg_n else None,	# hipEvents around the ncclGroup, rank 0
-                "exchanges_timed": xchg_n,
-                "k1_busy_ms_per_launch_per_rank": {"min": min(k1_busy_ranks), "max": max(k1_busy_ranks), "all": k1_busy_ranks},
-                "exchange": "none" if (sf is None or not sf.active) else
-                            ("native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
-                             "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else
-                                                               "one ncclGroup of three all-reduces", F))
-                            if sf.exchange == "rccl" else
-                            "torch.distributed all-reduces (RCCL) of hit counts / live sum / max once per frame of %d batches per GPU" % F,
-            },
-            "roofline": {"bound": "hbm", "kernel": k1_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "k1_busy_ms_per_launch": k1_busy, "k1_ms_per_launch": k1_ms, "k1_launches": launches[0],
-                         "k1_overlap": (ms[0] / busy[0]) if busy[0] > 0 else None,
-                         "achieved_plain_average": achieved_plain, "frac_plain_average": achieved_plain / HBM_PEAK_GBS,
-                         "accounting": "K1s of consecutive sub-launches run on two streams and overlap at their edges: achieved = "
-                                       "algorithmic bytes of all K1 launches / time with at least one K1 running (union of the "
-                                       "hipEvent intervals); *_plain_average divides by the mean individual duration, which counts "
-                                       "the shared time twice",
-                         "whole_path_frac": value * 1e6 * bytes_per_sample / 1e9 / HBM_PEAK_GBS / max(1, world),
-                         # also against what the part delivers (6.29 TB/s float4 copy, MI355X_MICROARCH.md)
-                         "frac_of_achievable": achieved / ACHIEVABLE_GBS,
-                         "k1_traffic_rate_GBs": (traffic / 1e9 / (k1_busy * 1e-3)) if (traffic and k1_busy > 0) else None,
-                         "k2_ms_per_launch": ms_all[1] / max(1, n_all[1]),
-                         "k3_ms_per_launch": ms_all[2] / max(1, n_all[2]),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "unique_bytes_per_launch": alg_bytes / over,
-                         "isolated": isolated,
-                         "traffic_twin": None if not twin_ms else {
-                             "ms_per_launch": twin_ms,
-                             "k1_isolated_over_twin": (iso / twin_ms) if iso else None,
-                             "note": "a kernel with K1's loads (same tile order, prefetch depth) and stores but no arithmetic, "
-                                     "same buffers: the practical floor the memory system sets for one K1 launch"}},
-        }
-        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
-            out["cpu_baseline"] = cpu_baseline(bins, args.cpu_seconds)
-        # RCCL prints a version banner through C stdio, which would otherwise be flushed after this line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+                    "waterfall": "dead-store rule: a row that a later spectrum of the same call overwrites is not stored, "
+                                 "so a step stores the rows of its last %d of %d spectra (the ring ends in the same state; "
+                                 "the reference would store all of them)" % (min(wf_rows, F * spb), F * spb),
+                    "input_ordering": "strict" if args.strict_ordering else "relaxed",
+                    "strict_ordering_value": strict_value,	# MSamples/s of the same steps with the default (strict) ordering, untimed extra pass
+                    "host_submit_fraction": t_submit / elapsed,
+                    # multi-GPU self-description: what the exchange actually spanned, as the transport itself reports it
+                    "transport": ("none" if (sf is None or not sf.active) else
+                                  "native RCCL (library communicator)" if sf.exchange == "rccl" else "torch.distributed (%s)" % dist.get_backend()),
+                    "transport_agreement": transport,
+                    "exchange_ranks": exchange_ranks,			# ncclCommCount(library communicator) on rank 0 (1 = no exchange)
+                    "exchange_ranks_per_rank": xchg_ranks_all,
+                    "exchange_ms_per_frame": (xchg_ms / xchg_n) if xchg_n else None,	# hipEvents around the ncclGroup, rank 0
+                    "exchanges_timed": xchg_n,
+                    "k1_busy_ms_per_launch_per_rank": {"min": min(k1_busy_ranks), "max": max(k1_busy_ranks), "all": k1_busy_ranks},
+                    "exchange": "none" if (sf is None or not sf.active) else
+                                ("native RCCL (%s) of hit counts / live sum / max once per frame of %d batches per GPU, on the "
+                                 "library's count/merge stream" % ("reduce-scatter + sliced merge" if sf.sliced else
+                                                                   "one ncclGroup of three all-reduces", F))
+                                if sf.exchange == "rccl" else
+                                "torch.distributed all-reduces (RCCL) of hit counts / live sum / max once per frame of %d batches per GPU" % F,
+                },
+                "roofline": roofline,
+            }
 
-    # orderly shutdown on every rank: the library's communicator and instance first, then torch's process group
+    # orderly shutdown on every rank: the library's communicator and instance first (torch's process group: the caller)
     try:
         if sf is not None:
             sf.close()
@@ -500,6 +609,74 @@ def main():
             f.close()
     except Exception as e:
         sys.stderr.write("rank %d: shutdown: %s\n" % (rank, e))
+    del iq
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher started us: become the launcher's parent (child process; nothing in THIS process has touched the GPU)
+        sys.exit(self_launch(args))
+    # The library's two FFT streams must not share a hardware queue with each other or with RCCL's streams
+    # (HIP maps streams onto 4 queues by default; DESIGN.md section 5 "Hardware queues"): neutral at N=1 (measured).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FOSPHOR_BENCH_ONE_GPU"):		# test hook: every rank on device 0 (tests/test_gpu_dist.py, with the gloo backend)
+        local_rank = 0
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d: measuring with %d ranks\n" % (args.gpus, world, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        # (FOSPHOR_BENCH_BACKEND=gloo: test hook -- several ranks sharing ONE GPU, which RCCL refuses; tests/test_gpu_dist.py)
+        backend = os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    from _pkg import gr_fosphor_amd
+    ctx = {"torch": torch, "dist": dist, "pkg": gr_fosphor_amd, "world": world, "rank": rank}
+
+    out = measure(args.config, args, ctx, args.steps, args.warmup)
+
+    if world == 1 and args.config == "C2" and not args.no_other_configs and args.mode in ("auto", "batch") \
+            and not args.bins and not args.batches_per_step:
+        # The other single-GPU BASELINE configurations, in the same process, so that the driver's clock has seen them too
+        # (each: its own instance and input ring, a short pre-conditioning, `--other-steps` timed steps of bench.py --config Cx)
+        others = {}
+        for name in ("C3", "C5"):
+            try:
+                others[name] = measure(name, args, ctx, args.other_steps, 5, light=True)
+            except Exception as e:
+                others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            # C3 in calls of 4 batches (the call size of rounds 1-3; too few tiles for the FFT launch to share the chip)
+            c3_4 = measure("C3", args, ctx, args.other_steps, 5, light=True, batches_per_step=4)
+            if isinstance(others.get("C3"), dict) and "value" in others["C3"]:
+                others["C3"]["four_batch_call_value"] = c3_4["value"]
+        except Exception as e:
+            sys.stderr.write("bench.py: C3 with 4-batch calls: %s\n" % e)
+        if out is not None:
+            out["other_configs"] = others
+
+    if rank == 0 and out is not None:
+        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
+            out["cpu_baseline"] = cpu_baseline((args.bins or CONFIGS["C2"]["bins"]), args.cpu_seconds)
+        # RCCL prints a version banner through C stdio, which would otherwise be flushed after this line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

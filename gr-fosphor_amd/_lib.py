@@ -114,6 +114,7 @@ SIGNATURES = {
     "fosphor_amd_upload_stream": (C.c_void_p, [C.c_void_p]),
     "fosphor_amd_tune_placement": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "fosphor_amd_plan_piece_batches": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong]),
+    "fosphor_amd_share_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "fosphor_amd_version": (C.c_char_p, []),
     # include/fosphor_amd_axis.h
     "fosphor_amd_freq_axis_build": (None, [C.c_void_p, C.c_double, C.c_double, C.c_int]),
@@ -144,6 +145,7 @@ SIGNATURES = {
     "fosphor_amd_sink_new_len": (C.c_void_p, [C.c_int]),
     "fosphor_amd_sink_feed": (C.c_double, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fosphor_amd_sink_free": (None, [C.c_void_p]),
+    "fosphor_amd_sink_dropped": (C.c_uint64, [C.c_void_p]),
     "fosphor_amd_sink_start": (C.c_int, [C.c_void_p]),
     "fosphor_amd_sink_stop": (C.c_int, [C.c_void_p]),
     "fosphor_amd_sink_work": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

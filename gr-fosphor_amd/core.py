@@ -226,6 +226,14 @@ class Fosphor:
             raise RuntimeError("fosphor_amd_exchange_time -> %d" % rv)
         return ms.value, n.value
 
+    def share_stats(self):
+        """fosphor_amd_share_stats: (FFT launches in the space-sharing form, in the full-chip form, work-groups of the shared form)"""
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_int()
+        rv = self.L.fosphor_amd_share_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        if rv:
+            raise RuntimeError("fosphor_amd_share_stats -> %d" % rv)
+        return a.value, b.value, c.value
+
     def kernel_busy(self):
         """ms during which >= 1 kernel of each kind ran (call before kernel_times)"""
         ms = (C.c_float * 3)()

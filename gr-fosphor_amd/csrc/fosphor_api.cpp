@@ -116,6 +116,17 @@ struct fosphor
 	int       set_used[kSets];
 	int       overlap;			/* 1: two-stream pipeline for process paths */
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum (what odd hops use) */
+	/* tuning / test knobs, read from the environment ONCE, at init (nothing on the submit path calls getenv) */
+	int       kn_tile;			/* FOSPHOR_AMD_TILE: spectra per tile, 0 = pick_tile's choice */
+	int       kn_no_bigchunk;		/* FOSPHOR_AMD_NO_BIGCHUNK */
+	int       kn_rowmask_off;		/* FOSPHOR_AMD_ROWMASK=0: dense count hand-off at N = 65536 */
+	int       kn_no_sum16;			/* FOSPHOR_AMD_NO_SUM16 */
+	int       kn_frame_group;		/* FOSPHOR_AMD_FRAME_GROUP: chunks per count work-group of a sharded frame (default 4) */
+	int       kn_k1w_off;			/* FOSPHOR_AMD_K1W=0: the general kernel at N = 8192 */
+	int       kn_k1w_share_off;		/* FOSPHOR_AMD_K1W_SHARE=0: no space sharing at N = 8192 */
+	int       n_cus;			/* hipDeviceProp_t::multiProcessorCount */
+	int       share_cus;			/* N = 8192: work-groups of an FFT launch that leaves CUs to the count / merge kernels (0: never) */
+	long long k1w_shared, k1w_full;		/* N = 8192: FFT launches made in the shared / the full-chip form (fosphor_amd_share_stats) */
 	uint32_t *d_hc;
 	uint32_t *d_hc_export;			/* [n_bins][N] last batch, written by K3 on the 16-bit path */
 	const uint16_t *export_src;		/* ... made from the last batch's slabs when fosphor_amd_get_buffers asks */
@@ -425,21 +436,41 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	} else {
 		HIP_TRY(hipGetDevice(&self->device), "hipGetDevice");
 	}
+	{
+		hipDeviceProp_t prop;
+		HIP_TRY(hipGetDeviceProperties(&prop, self->device), "hipGetDeviceProperties");
+		self->n_cus = prop.multiProcessorCount;
+		/* space sharing is laid out for the whole MI355X (256 CUs: 224 + 32); any other CU count -- a partitioned part -- runs
+		 * every launch in the full-chip form */
+		self->share_cus = (self->n_cus == 256) ? kK1wShareCus : 0;
+	}
+	{
+		const char *e;
+		e = getenv("FOSPHOR_AMD_TILE");        self->kn_tile = e ? atoi(e) : 0;
+		self->kn_no_bigchunk = getenv("FOSPHOR_AMD_NO_BIGCHUNK") != NULL;
+		e = getenv("FOSPHOR_AMD_ROWMASK");     self->kn_rowmask_off = (e && *e == '0');
+		self->kn_no_sum16 = getenv("FOSPHOR_AMD_NO_SUM16") != NULL;
+		e = getenv("FOSPHOR_AMD_FRAME_GROUP"); self->kn_frame_group = e ? atoi(e) : 4;
+		e = getenv("FOSPHOR_AMD_K1W");         self->kn_k1w_off = (e && *e == '0');
+		e = getenv("FOSPHOR_AMD_K1W_SHARE");   self->kn_k1w_share_off = (e && *e == '0');
+	}
 
-	/* Measurement only (profiles/r04_ceiling.md): FOSPHOR_AMD_DBG_CUMASK=k reserves k CUs (k / 8 per XCD; mask bit i is CU i / 8 of
+	/* Measurement only, probe builds (-DFOSPHOR_AMD_PROBES; profiles/r04_ceiling.md): FOSPHOR_AMD_DBG_CUMASK=k reserves k CUs (k / 8 per XCD; mask bit i is CU i / 8 of
 	 * XCD i % 8, tools/ubench/cu_mask_probe.hip) for the count / merge streams and confines every FFT stream -- including the
 	 * instance's main stream, which is then the library's own and not the caller's -- to the rest.  Space-sharing by mask
 	 * measured far worse than the hardware's own interleaving; nothing in the product path sets it. */
+#ifdef FOSPHOR_AMD_PROBES
 	{
 		const char *e = getenv("FOSPHOR_AMD_DBG_CUMASK");
 		cu_reserved = e ? atoi(e) : 0;
 		if (cu_reserved < 8 || cu_reserved > 128 || (cu_reserved & 7))
 			cu_reserved = 0;
-		for (int w = 0; w < 8; w++) {
-			const int lo = 32 * w, split = 256 - cu_reserved;
-			cu_mask_fft[w] = split >= lo + 32 ? ~0u : (split <= lo ? 0u : ((1u << (split - lo)) - 1u));
-			cu_mask_cnt[w] = ~cu_mask_fft[w];
-		}
+	}
+#endif
+	for (int w = 0; w < 8; w++) {
+		const int lo = 32 * w, split = 256 - cu_reserved;
+		cu_mask_fft[w] = split >= lo + 32 ? ~0u : (split <= lo ? 0u : ((1u << (split - lo)) - 1u));
+		cu_mask_cnt[w] = ~cu_mask_fft[w];
 	}
 	if (cfg && cfg->stream && !cu_reserved) {
 		self->stream = (hipStream_t)cfg->stream;
@@ -751,8 +782,7 @@ error:
  * sample written and read back, 16 was 0.5.  A tile never straddles a batch (K2 weights whole tiles). */
 static int pick_tile(const struct fosphor *self, int total, int batch)
 {
-	const char *e = getenv("FOSPHOR_AMD_TILE");
-	const int v = e ? atoi(e) : 0;
+	const int v = self->kn_tile;
 	if (v >= 4 && v <= (self->log2n == 16 ? 32 : 128) && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
 		return v;
 	if (self->log2n == 16 && self->k1h_fused) {
@@ -828,16 +858,21 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	k1->scratch = self->d_scratch;
 	k1->sync = (self->log2n == 16 && self->k1h_fused) ? self->d_k1h_sync : NULL;
 	k1->sync_err = self->h_k1h_err;
+#ifdef FOSPHOR_AMD_PROBES
 	{
 		static const int dbg = [] { const char *e = getenv("FOSPHOR_AMD_DBG_K1H"); return e ? atoi(e) : 0; }();
 		k1->dbg_k1h = dbg;
 	}
+#endif
 	k1->iq_half = self->iq_half;
+	k1->n_cus = self->n_cus;
+	k1->k1w_off = self->kn_k1w_off;
 	{
-		static const bool share = [] { const char *e = getenv("FOSPHOR_AMD_K1W_SHARE"); return !(e && *e == '0'); }();
-		k1->cus = (self->log2n == 13 && self->overlap && share && tile > 0 && (total / tile) % kK1wShareCus == 0) ? kK1wShareCus : 0;
+		const int sc = self->share_cus;
+		k1->cus = (self->log2n == 13 && self->overlap && !self->kn_k1w_share_off && sc > 0 && tile > 0 && (total / tile) % sc == 0) ? sc : 0;
 		/* ... when there is a tail to share with: the count / merge kernels of the launch before this one are still queued or running
-		 * (calls issued back to back).  A launch that finds the chip idle takes all of it. */
+		 * (calls issued back to back).  A launch that finds the chip idle takes all of it.  (The choice depends on timing; the results
+		 * do not: the tile loop is grid-stride.  fosphor_amd_share_stats reports how many launches took which form.) */
 		if (k1->cus && !(self->tail_set && hipEventQuery(self->ev_tail) == hipErrorNotReady))
 			k1->cus = 0;
 	}
@@ -850,7 +885,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
  * then reads slab-major 16-bit counts (0.5 B per cell) instead of 32-bit sums of per-chunk slabs. */
 static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
 {
-	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !getenv("FOSPHOR_AMD_NO_BIGCHUNK");
+	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !self->kn_no_bigchunk;
 }
 
 /* Sparse K2 -> K3 hand-off (row masks + hot flags) for the large state of N = 65536 (128 MiB, one batch = one frame: +10 % for
@@ -859,8 +894,7 @@ static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
  * (the tests run both). */
 static int use_rowmask(const struct fosphor *self)
 {
-	const char *e = getenv("FOSPHOR_AMD_ROWMASK");
-	return self->log2n == 16 && !(e && *e == '0');
+	return self->log2n == 16 && !self->kn_rowmask_off;
 }
 
 static int gcd_int(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
@@ -901,7 +935,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	 * a display frame): K2 leaves per-chunk packed 16-bit slabs in d_slab16 (no zeroing, no global atomics)
 	 * and k2c_sum adds each batch's slabs into its 32-bit array.  Needs whole chunks and room for the slabs. */
 	const int sum16 = (!use16 || batch > 1024) && chunk == 1024 && cpb > 1 && self->d_slab16 &&
-	                  n_batches * cpb <= self->slab_chunks && !getenv("FOSPHOR_AMD_NO_SUM16");
+	                  n_batches * cpb <= self->slab_chunks && !self->kn_no_sum16;
 
 	memset(&k2, 0, sizeof(k2));
 	k2.bins = self->d_bins; k2.partial = self->d_partial;
@@ -922,7 +956,12 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	k2.w = 1.0f - self->alpha;
 	k2.log2_w = (float)log2((double)(1.0f - self->alpha));
 	k2.t_offset = t_offset; k2.weight_batch = weight_batch;
-	k2.dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
+#ifdef FOSPHOR_AMD_PROBES
+	{
+		static const int dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
+		k2.dbg_same = dbg_same;
+	}
+#endif
 	if (cpb == 1) {
 		k2.chunk_sum = self->d_live_sum + (size_t)lslot * self->n;
 		k2.chunk_max = self->d_vmax + (size_t)lslot * self->n;
@@ -1026,7 +1065,12 @@ static int run_merge(struct fosphor *self, int n_batches, int batch, int slot0, 
 	k3.n_batches = n_batches; k3.batch = batch; k3.n_bins = self->n_bins; k3.n = self->n;
 	k3.t0r = self->t0r; k3.t0d = self->t0d; k3.alpha = self->alpha;
 	k3.cell_begin = cell_begin; k3.cell_end = cell_end;
-	k3.dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
+#ifdef FOSPHOR_AMD_PROBES
+	{
+		static const int dbg_same = getenv("FOSPHOR_AMD_DBG_SAME") != NULL;
+		k3.dbg_same = dbg_same;
+	}
+#endif
 	prof_begin(self, 2, st);
 	HIP_TRY(launch_k3(k3, st), "launch merge");
 	prof_end(self, st);
@@ -1090,8 +1134,14 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 	const int did_prep = self->win_dirty || self->thr_dirty || self->state == ST_BOOTING;
 	const int wf_first_global = total > self->wf_rows ? total - self->wf_rows : 0;
 	int sub_b, n_sub, use_alt, used_alt = 0;
-	/* measurement only (results are wrong): FOSPHOR_AMD_DBG_SKIP bit 0 = no K1, bit 1 = no count / merge, bit 2 = no K3, bit 3 = no K2 */
+	/* measurement only, probe builds (results are wrong): FOSPHOR_AMD_DBG_SKIP bit 0 = no K1, bit 1 = no count / merge, bit 2 = no K3,
+	 * bit 3 = no K2; FOSPHOR_AMD_DBG_NOWAIT: an FFT launch does not wait for the count kernel that still reads its intermediate set */
+#ifdef FOSPHOR_AMD_PROBES
 	static const int dbg_skip = [] { const char *e = getenv("FOSPHOR_AMD_DBG_SKIP"); return e ? atoi(e) : 0; }();
+	static const int dbg_nowait = getenv("FOSPHOR_AMD_DBG_NOWAIT") != NULL;
+#else
+	constexpr int dbg_skip = 0, dbg_nowait = 0;
+#endif
 
 	if (prepare(self))
 		return -EIO;
@@ -1135,7 +1185,7 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		self->pp = (self->pp + 1) % self->n_sets;
 		self->d_bins = self->d_bins_pp[set];
 		self->d_partial = self->d_partial_pp[set];
-		if (self->overlap && self->set_used[set] && !getenv("FOSPHOR_AMD_DBG_NOWAIT"))
+		if (self->overlap && self->set_used[set] && !dbg_nowait)
 			HIP_TRY(hipStreamWaitEvent(ks, self->ev_set_free[set], 0), "wait for intermediate set");
 		wf_first = wf_first_global - t0;
 		if (wf_first < 0) wf_first = 0;
@@ -1149,6 +1199,9 @@ static int run(struct fosphor *self, const void *d_iq, int n_batches, int batch,
 		if (!(dbg_skip & 1))
 			HIP_TRY(launch_k1(k1, ks), "launch fft_bin");
 		prof_end(self, ks);
+		if (self->log2n == 13) {
+			if (k1.cus) self->k1w_shared++; else self->k1w_full++;
+		}
 		if (stores_rows && wf_leave(self, ks))
 			return -EIO;
 
@@ -1250,6 +1303,13 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 	 * sink reuses immediately (base_sink_c_impl.cc:168-174: a latent race).  Here the samples
 	 * are copied into a pinned ring slot before returning, and the slot is recycled only when
 	 * its H2D copy has completed. */
+	/* (uploads queued by fosphor_amd_upload_pinned and not yet processed come first: the sample stream is applied in order, and a
+	 * pending upload may own the staging slot this call is about to fill) */
+	while (self->pend_n) {
+		const int rv = fosphor_amd_process_uploaded(self, NULL);
+		if (rv)
+			return rv;
+	}
 	k = self->stage_idx;
 	/* (each piece behind its own check: fosphor_amd_process_pinned shares d_stage / stage_free) */
 	if (!self->h_stage[k])
@@ -1270,6 +1330,7 @@ extern "C" int fosphor_process(struct fosphor *self, void *samples, int len)
 		 * d_stage[k]) has finished */
 		if (hipEventRecord(self->stage_free[k], self->stream) != hipSuccess && !rv)
 			rv = -EIO;
+		self->stage_used[k] = 1;		/* a later fosphor_amd_upload_pinned into this slot (its own stream) waits for stage_free[k] */
 		self->stage_idx ^= 1;
 		return rv;
 	}
@@ -1297,7 +1358,9 @@ extern "C" int fosphor_amd_upload_pinned(struct fosphor *self, const void *sampl
 
 	k = self->stage_idx;
 	if (self->d_stage[k] && self->d_stage_cap[k] < (size_t)len) {		/* grown on demand (behind everything that reads the old one) */
-		HIP_TRY(hipDeviceSynchronize(), "drain before regrowing the staging buffer");
+		/* (this instance's streams only: the caller's unrelated streams are not stalled) */
+		if (sync_all(self) || (self->copy_stream && hipStreamSynchronize(self->copy_stream) != hipSuccess))
+			return -EIO;
 		(void)hipFree(self->d_stage[k]);
 		self->d_stage[k] = NULL;
 	}
@@ -1542,7 +1605,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 		const int cpb = n_local / 1024;
 		const size_t cells = (size_t)self->n_bins * self->n;
 		const int chunked = (n_local % 1024) == 0 && cpb > 1 && self->d_slab16 && cpb <= self->slab_chunks &&
-		                    !getenv("FOSPHOR_AMD_NO_SUM16");
+		                    !self->kn_no_sum16;
 		long long per_chunk = 1024LL * self->n;
 		int sub_c = (int)(self->sub_samples / per_chunk);
 		if (sub_c < 1) sub_c = 1;
@@ -1554,8 +1617,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 			{
 				/* measured, N = 1024, 256 batches per frame: G = 1 / 2 / 4 / 8 -> 486 / 510 / 528 / 450 GSamples/s (at 8 the
 				 * count kernel's 128 work-groups no longer keep up with the FFT kernel) */
-				const char *e = getenv("FOSPHOR_AMD_FRAME_GROUP");
-				for (int want = e ? atoi(e) : 4; want >= 1; want >>= 1)
+				for (int want = self->kn_frame_group; want >= 1; want >>= 1)
 					if (want <= 32 && !(want & (want - 1)) && sub_c % want == 0 && cpb % want == 0) {
 						G = want;
 						break;
@@ -2021,7 +2083,6 @@ extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_sa
 	int reallocs = 0;
 	float worst_before = 0.0f, worst_after = 0.0f;
 	uint32_t *const cur_bins = self->d_bins;
-	float2 *const cur_part = self->d_partial;
 	int cur_set = 0;
 	for (int i = 0; i < kSets; i++)
 		if (self->d_bins_pp[i] == cur_bins) cur_set = i;
@@ -2059,7 +2120,11 @@ extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_sa
 				self->d_bins_pp[i] = ob; self->d_partial_pp[i] = op;	/* keep what we had */
 				rejected.push_back(nb); rejected.push_back(np);
 			}
+#ifdef FOSPHOR_AMD_PROBES
 			static const int tune_all = [] { const char *e = getenv("FOSPHOR_AMD_DBG_TUNE_ALL"); return e ? atoi(e) : 0; }();
+#else
+			constexpr int tune_all = 0;
+#endif
 			if (best <= good_ms && t + 1 >= tune_all)
 				break;
 		}
@@ -2072,6 +2137,20 @@ extern "C" int fosphor_amd_tune_placement(struct fosphor *self, const void *d_sa
 	if (us_before) *us_before = worst_before * 1e3f;
 	if (us_after) *us_after = worst_after * 1e3f;
 	return reallocs;
+}
+
+/* N = 8192: how many FFT launches ran in the space-sharing form (share_cus work-groups, beside the previous launch's count / merge
+ * kernels) and how many took every CU, since the instance was made; cus = the shared form's work-group count (0: this device never
+ * shares).  The form is chosen from the state of the queue at submit time, so two runs of the same calls may differ here -- never in
+ * their results. */
+extern "C" int fosphor_amd_share_stats(struct fosphor *self, long long *shared, long long *full, int *cus)
+{
+	if (!self)
+		return -EINVAL;
+	if (shared) *shared = self->k1w_shared;
+	if (full) *full = self->k1w_full;
+	if (cus) *cus = self->share_cus;
+	return 0;
 }
 
 extern "C" void *fosphor_amd_stream(struct fosphor *self)

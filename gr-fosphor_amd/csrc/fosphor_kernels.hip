@@ -28,6 +28,16 @@
 
 namespace fosphor_amd {
 
+/* Measurement switches that give WRONG RESULTS BY CONSTRUCTION (kernel parts skipped, chunks aliased) exist only in probe builds
+ * (-DFOSPHOR_AMD_PROBES, tools/r04_ceiling_build.sh): in the product library they are the constant 0 and the code behind them is gone. */
+#ifdef FOSPHOR_AMD_PROBES
+#define PROBE_K1H(p)  ((p).dbg_k1h)
+#define PROBE_SAME(p) ((p).dbg_same)
+#else
+#define PROBE_K1H(p)  0
+#define PROBE_SAME(p) 0
+#endif
+
 /* ------------------------------------------------------------------------ */
 /* Complex helpers: same operations, same order as fft.cl                   */
 /* ------------------------------------------------------------------------ */
@@ -1667,15 +1677,15 @@ void k1h_fused(const K1Params p)
 	const uint32_t iq_vo = 1024u * (unsigned)(lane >> 3) + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
 	const int in_rd  = ia * 32 + ((wv ^ (ia & 7)) << 2) + sa;	/* + 512 j: row m = ia + 16 j, residue 4 wave + sa (dwords) */
 	const uint32_t inb_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)inb;
-	if (p.dbg_k1h & 2)			/* (measurement only: noise-like input that is never loaded) */
+	if (PROBE_K1H(p) & 2)			/* (measurement only: noise-like input that is never loaded) */
 		for (int e = tid; e < 2 * kInLen; e += 512)
 			inb[e] = ((0x211fu + 977u * e) & 0x3fffu) | 0x20000000u | (((0x2c11u + 131u * e) & 0x3fffu) << 16) | ((e & 1u) << 15) | ((e & 2u) << 30);
 	auto fetch_iq = [&](int t, int buf) {		/* row groups g = wave, wave + 7, ... < 32 (8 rows each) into buffer `buf`; the last wave
 							 * requests nothing: it polls the cluster counters, and a poll returns behind whatever
 							 * its wave has in flight */
-		if (!HALF || (p.dbg_k1h & 2) || wv == 7)
+		if (!HALF || (PROBE_K1H(p) & 2) || wv == 7)
 			return;
-		if (p.dbg_k1h & 32) t = gc;	/* (measurement only: the same rows again and again) */
+		if (PROBE_K1H(p) & 32) t = gc;	/* (measurement only: the same rows again and again) */
 		/* global_load_lds_dwordx4 by hand: the compiler parks every LDS read and every __syncthreads() that follows an LDS-DMA it
 		 * knows about behind s_waitcnt vmcnt(0) -- the request would be waited for at the very next barrier instead of an iteration
 		 * later.  Whoever reads the buffer is behind an explicit `s_waitcnt vmcnt(..)` of the requesting wave and a barrier. */
@@ -1701,7 +1711,7 @@ void k1h_fused(const K1Params p)
 				const uint32_t raw = inb[buf * kInLen + in_rd + 512 * j];
 				const h2 h = __builtin_bit_cast(h2, raw);
 				xv = v2f{ (float)h.x, (float)h.y };		/* v_cvt_f32_f16: exact */
-			} else if (p.dbg_k1h & 2) {
+			} else if (PROBE_K1H(p) & 2) {
 				xv = v2f{ 0.01f * (float)(((tid * 37 + j * 11) & 63) - 32), 0.01f * (float)(((tid * 29 + j * 7) & 63) - 31) };
 			} else {
 				xv = bld_v2f<kAuxNT>(rs_f, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
@@ -1785,7 +1795,7 @@ void k1h_fused(const K1Params p)
 		/* (every member has read the previous spectrum out of the intermediate: the last wave looked before its epilogue)
 		 * every read of the stage-B exchange array is done -- stage A writes the same memory */
 		wg_barrier_lds();
-		if (!(p.dbg_k1h & 8)) {
+		if (!(PROBE_K1H(p) & 8)) {
 			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
 			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
 			 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
@@ -1807,7 +1817,7 @@ void k1h_fused(const K1Params p)
 				ra[j] = c_mul(ra[j], twa_t[ia * 15 + j - 1]);
 		}
 
-		if (tid == 0 && !(p.dbg_k1h & 1)) {
+		if (tid == 0 && !(PROBE_K1H(p) & 1)) {
 			uint32_t spins = 0;
 			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0) {
 				if (++spins > kSpinLimit) { *p.sync_err = 0x80000003u; break; }
@@ -1819,7 +1829,7 @@ void k1h_fused(const K1Params p)
 
 		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
 		v2f r[16];
-		if (!(p.dbg_k1h & 8)) {
+		if (!(PROBE_K1H(p) & 8)) {
 			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
 #pragma unroll
 			for (int j = 0; j < 16; j++)
@@ -1857,7 +1867,7 @@ void k1h_fused(const K1Params p)
 
 		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
 		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them */
-		if (tid == 448 && !(p.dbg_k1h & 1)) {
+		if (tid == 448 && !(PROBE_K1H(p) & 1)) {
 			uint32_t spins = 0;
 			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
 				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
@@ -1872,7 +1882,7 @@ void k1h_fused(const K1Params p)
 		}
 
 		/* epilogue (display.cl:136-150,161-168), 9-bit bin indices: low byte into the quad's dword, 9th bit into the tile's */
-		const bool store_row = (t >= p.wf_first) && !(p.dbg_k1h & 4);
+		const bool store_row = (t >= p.wf_first) && !(PROBE_K1H(p) & 4);
 		const uint32_t wf_so = (uint32_t)((p.wf_pos0 + t) & p.wf_mask) * (uint32_t)(N * 4);
 		const int sh8 = 8 * (u & 3);
 		/* four samples at a time: fast path, ONE branch for the four (rare: some sample is not provably exact -- find it again and
@@ -1888,7 +1898,7 @@ void k1h_fused(const K1Params p)
 				amb = amb > ab ? amb : ab;		/* v_max_u32: NaN / inf order above every finite measure */
 				bng[k] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
 			}
-			if (amb > __float_as_uint(bk.amb) && !(p.dbg_k1h & 16)) {
+			if (amb > __float_as_uint(bk.amb) && !(PROBE_K1H(p) & 16)) {
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const v2f x = r[R16_PERM(4 * g + k)];
@@ -1916,7 +1926,7 @@ void k1h_fused(const K1Params p)
 					__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, K1H_OUT_AUX);
 			}
 		}
-		if ((u & 3) == 3 && !(p.dbg_k1h & 4)) {
+		if ((u & 3) == 3 && !(PROBE_K1H(p) & 4)) {
 			const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(bins_lo + (size_t)(t >> 2) * N);
 #pragma unroll
 			for (int c = 0; c < 16; c++) {
@@ -1925,7 +1935,7 @@ void k1h_fused(const K1Params p)
 			}
 		}
 	}
-	if (!(p.dbg_k1h & 4)) {
+	if (!(PROBE_K1H(p) & 4)) {
 		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
 #pragma unroll
 		for (int c = 0; c < 16; c++)
@@ -1990,9 +2000,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			return hipErrorInvalidValue;
 		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); needs 16-byte aligned
 		 * windows (even hop).  FOSPHOR_AMD_K1W=0: the general kernel. */
-		const char *k1w_env = getenv("FOSPHOR_AMD_K1W");
-		const bool k1w_on = !(k1w_env && *k1w_env == '0');
-		if (k1w_on && !(p.hop & 1)) {
+		if (!p.k1w_off && !(p.hop & 1)) {
 			constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
 			static bool attr_w = false;
 			if (!attr_w) {
@@ -2005,7 +2013,8 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			}
 			/* one 8-wave work-group per CU -- or per CU of the share the host leaves to this kernel (K1Params.cus: the count and
 			 * merge kernels of the previous launch run on the rest) */
-			const int cus = (p.cus > 0 && p.cus < 256 && tiles % p.cus == 0) ? p.cus : 256;
+			const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
+			const int cus = (p.cus > 0 && p.cus < all_cus && tiles % p.cus == 0) ? p.cus : all_cus;
 			const int bw = tiles < cus ? tiles : cus;
 			if (p.fft_out)
 				hipLaunchKernelGGL(k1w_fft_bin<true>, dim3(bw), dim3(512), ldsw, s, p);
@@ -2015,7 +2024,8 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		}
 		constexpr int N = 8192;
 		constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;	/* exchange slab + twiddle table + window: 160 KiB */
-		int blocks = tiles < 256 ? tiles : 256;		/* one work-group (16 waves, 128 VGPRs) per CU */
+		const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
+		int blocks = tiles < all_cus ? tiles : all_cus;		/* one work-group (16 waves, 128 VGPRs) per CU */
 		if (!attr_set) {
 			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
 			                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -2125,7 +2135,7 @@ void k2_count(const K2Params p)
 								 * load cost a v_mul_lo_u32 and a 64-bit add: 23 instead of 31 VGPRs, 2 instead of 22
 								 * v_mul_lo_u32; the kernel's time did not change, it does not wait for its VALUs) */
 	const int x0   = blockIdx.x * 64;
-	const int c    = p.dbg_same ? 0 : blockIdx.y;	/* chunk index within the launch */
+	const int c    = PROBE_SAME(p) ? 0 : blockIdx.y;	/* chunk index within the launch */
 	const int cpb  = p.batch / p.chunk;		/* chunks per batch */
 	const int f    = c / cpb;			/* batch index */
 	const int t_in = (c - f * cpb) * p.chunk;	/* first spectrum of the chunk within its batch */
@@ -2522,7 +2532,7 @@ void k3_merge(const K3Params p)
 #pragma unroll
 					for (int u = 0; u < U; u++)
 						hc[r][u] = (ok && u < fe && ((e[r] >> (20 + u)) & 1u))
-						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : u) * cells + row * 64 + lane]) : 0u;
+						        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(PROBE_SAME(p) ? 0 : u) * cells + row * 64 + lane]) : 0u;
 				}
 			};
 			entries(idx, e_c);
@@ -2593,7 +2603,7 @@ void k3_merge(const K3Params p)
 #pragma unroll
 					for (int r = 0; r < R; r++) {
 						const uint32_t wd = (valid[r] && fl < p.n_batches)
-						        ? p.rowmask[((size_t)slab[r] * p.mask_words + (bin[r] >> 5)) * p.mask_stride + (p.dbg_same ? 0 : fl)] : 0u;
+						        ? p.rowmask[((size_t)slab[r] * p.mask_words + (bin[r] >> 5)) * p.mask_stride + (PROBE_SAME(p) ? 0 : fl)] : 0u;
 						m[r] = __ballot((wd >> (bin[r] & 31)) & 1u);
 					}
 				}
@@ -2605,7 +2615,7 @@ void k3_merge(const K3Params p)
 #pragma unroll
 						for (int u = 0; u < U; u++)
 							hc[r][u] = (f + u < fe && ((m[r] >> (f + u - f0)) & 1ull))
-							        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid[r]]) : 0u;
+							        ? (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(PROBE_SAME(p) ? 0 : f + u) * cells + gid[r]]) : 0u;
 #pragma unroll
 					for (int r = 0; r < R; r++)
 #pragma unroll
@@ -2659,7 +2669,7 @@ void k3_merge(const K3Params p)
 				hv0[r][1] = p.hist[ok ? hidx[r] + 32 : 0];
 #pragma unroll
 				for (int f = 0; f < 4; f++)
-					hc[r][f] = (f < fe) ? __builtin_nontemporal_load(&hc32[(size_t)(p.dbg_same ? 0 : f) * pairs + gg]) : 0u;
+					hc[r][f] = (f < fe) ? __builtin_nontemporal_load(&hc32[(size_t)(PROBE_SAME(p) ? 0 : f) * pairs + gg]) : 0u;
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
@@ -2708,7 +2718,7 @@ void k3_merge(const K3Params p)
 					uint32_t hc[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++)
-						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
+						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(PROBE_SAME(p) ? 0 : f + u) * cells + gid]);
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {	/* display.cl:237-238 */
@@ -2724,7 +2734,7 @@ void k3_merge(const K3Params p)
 					uint32_t hc[4];
 #pragma unroll
 					for (int u = 0; u < 4; u++)
-						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(p.dbg_same ? 0 : f + u) * cells + gid]);
+						hc[u] = (uint32_t)__builtin_nontemporal_load(&p.hc16[(size_t)(PROBE_SAME(p) ? 0 : f + u) * cells + gid]);
 #pragma unroll
 					for (int u = 0; u < 4; u++) {
 						if (!((hv <= 0.01f) && (hc[u] == 0))) {
@@ -2737,7 +2747,7 @@ void k3_merge(const K3Params p)
 					f += 4;
 				}
 				for (; f < fe; f++) {
-					const uint32_t hc = (uint32_t)p.hc16[(size_t)(p.dbg_same ? 0 : f) * cells + gid];
+					const uint32_t hc = (uint32_t)p.hc16[(size_t)(PROBE_SAME(p) ? 0 : f) * cells + gid];
 					if (!((hv <= 0.01f) && (hc == 0))) {
 						const float2 de = rise_in_lds ? rise_lds[hc] : p.rise[hc];
 						hv = (hv - de.x) * de.y + de.x;
@@ -2843,7 +2853,7 @@ void k3_scan(const K3Params p)
 			const uint32_t *mw = p.rowmask + ((size_t)slab * p.mask_words + (bin >> 5)) * p.mask_stride;
 			uint32_t any = 0;
 			for (int f = 0; f < p.n_batches; f++) {
-				const uint32_t b = (mw[p.dbg_same ? 0 : f] >> (bin & 31)) & 1u;
+				const uint32_t b = (mw[PROBE_SAME(p) ? 0 : f] >> (bin & 31)) & 1u;
 				any |= b;
 				if (carry)
 					bits[k] |= b << f;

@@ -5,11 +5,19 @@
  * sink_runtime:  lib/base_sink_c_impl.{h,cc} -- work(), worker(), render(), settings, UI actions
  */
 #include <errno.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <chrono>
 
+#include <thread>
+
+#if defined(__x86_64__)
 #include <immintrin.h>
+#define FOSPHOR_CPU_RELAX() _mm_pause()
+#else
+#define FOSPHOR_CPU_RELAX() std::this_thread::yield()
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -137,7 +145,7 @@ sink_runtime::sink_runtime(int fifo_length)
     d_pending(0),
     d_have_window(false), d_frames(0), d_samples(0),
     d_inflight_head(0), d_inflight_n(0), d_inflight_samples(0), d_batches_per_call(1),
-    d_copy_gen(0), d_copy_pending(0), d_copy_sleepers(0), d_copy_quit(false)
+    d_copy_gen(0), d_copy_pending(0), d_copy_sleepers(0), d_copy_quit(false), d_dropped(0), d_drop_reported(false)
 {
 	d_ui = ui_state{ 1024, 1024, 0, 3, false, 0.5, 0.2, 0.35f, 0.0, 1.0 };
 	d_fifo = new fifo(fifo_length, true);				/* base_sink_c_impl.cc:58 */
@@ -173,6 +181,7 @@ sink_runtime::~sink_runtime()
 /* Host copy into the pinned ring with non-temporal stores: the destination is read next by the DMA engine, so the lines
  * need not be fetched for ownership nor kept in the core's caches (a third less memory traffic than memcpy's plain
  * stores, and the source stays cached).  32-byte AVX stores where the CPU has them, memcpy otherwise. */
+#if defined(__x86_64__)
 __attribute__((target("avx")))
 static void stream_copy_avx(void *dst, const void *src, size_t bytes)
 {
@@ -200,13 +209,18 @@ static void stream_copy_avx(void *dst, const void *src, size_t bytes)
 	memcpy(d + i, s + i, bytes - i);
 }
 
+#endif
+
 static void stream_copy(void *dst, const void *src, size_t bytes)
 {
+#if defined(__x86_64__)
 	static const bool have_avx = __builtin_cpu_supports("avx");
-	if (have_avx)
+	if (have_avx) {
 		stream_copy_avx(dst, src, bytes);
-	else
-		memcpy(dst, src, bytes);
+		return;
+	}
+#endif
+	memcpy(dst, src, bytes);		/* other hosts: plain copy */
 }
 
 void sink_runtime::copy_helper(int idx)
@@ -217,7 +231,7 @@ void sink_runtime::copy_helper(int idx)
 		const auto t_idle = std::chrono::steady_clock::now();
 		int spins = 0;
 		while (d_copy_gen.load(std::memory_order_acquire) == seen && !d_copy_quit.load(std::memory_order_relaxed)) {
-			_mm_pause();
+			FOSPHOR_CPU_RELAX();
 			if ((++spins & 255) == 0 &&
 			    std::chrono::steady_clock::now() - t_idle > std::chrono::microseconds(50)) {
 				std::unique_lock<std::mutex> lock(d_copy_mutex);
@@ -361,8 +375,11 @@ bool sink_runtime::execute_mouse_action(mouse_action_t action, int x, int y, dou
 	 * (get_render, another mouse action) or take its time without stalling the worker */
 	if (freq)
 		*freq = f;
-	if (d_freq_cb)
-		d_freq_cb(f, d_freq_user);
+	void (*cb)(double, void *);
+	void *user;
+	{ std::lock_guard<std::mutex> lk(d_ui_mutex); cb = d_freq_cb; user = d_freq_user; }	/* the pair as one snapshot */
+	if (cb)
+		cb(f, user);
 	return true;
 }
 
@@ -454,6 +471,15 @@ void sink_runtime::render()						/* :130-201 */
 				rv = fosphor_amd_upload_pinned(d_fosphor, data, len);
 				if (rv == -EBUSY)
 					break;				/* both staging buffers hold uploads: their kernels come first (next pass) */
+				if (rv) {
+					/* the region is given back unprocessed (the reference ignores fosphor_process's code, :170): counted, and
+					 * said once, so that a failing device does not pass for a quiet one */
+					d_dropped += (uint64_t)len;
+					if (!d_drop_reported) {
+						fprintf(stderr, "[!] fosphor_amd sink: upload failed (%d); samples are being dropped\n", rv);
+						d_drop_reported = true;
+					}
+				}
 				if (!d_events[slot]) {
 					hipEvent_t e;
 					if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
@@ -467,6 +493,8 @@ void sink_runtime::render()						/* :130-201 */
 				rv = fosphor_process(d_fosphor, data, len);	/* copies before it returns */
 				if (rv == 0)
 					d_samples += (uint64_t)len;
+				else
+					d_dropped += (uint64_t)len;
 			}
 		}
 		d_inflight[slot].event = ev;
@@ -522,8 +550,14 @@ int sink_runtime::work(int noutput_items, const std::complex<float> *in)	/* :432
 			d_copy_cv.notify_all();
 		}
 		stream_copy(dst, in, sizeof(std::complex<float>) * part);
-		while (d_copy_pending.load(std::memory_order_acquire))
-			_mm_pause();
+		/* the helpers finish within microseconds of this thread's own part; on an oversubscribed host a helper may have been
+		 * descheduled -- after a bounded spin the producer yields its core instead of burning it */
+		for (unsigned spins = 0; d_copy_pending.load(std::memory_order_acquire); ) {
+			if (++spins < 4096)
+				FOSPHOR_CPU_RELAX();
+			else
+				std::this_thread::yield();
+		}
 	} else {
 		memcpy(dst, in, sizeof(std::complex<float>) * (size_t)l);
 	}
@@ -700,6 +734,7 @@ double fosphor_amd_sink_feed(fosphor_amd_sink *s, const void *samples, int n, in
 	return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 void  fosphor_amd_sink_free(fosphor_amd_sink *s) { delete s; }
+uint64_t fosphor_amd_sink_dropped(fosphor_amd_sink *s) { return s->s.samples_dropped(); }
 int   fosphor_amd_sink_start(fosphor_amd_sink *s) { return s->s.start() ? 1 : 0; }
 int   fosphor_amd_sink_stop(fosphor_amd_sink *s) { return s->s.stop() ? 1 : 0; }
 int   fosphor_amd_sink_work(fosphor_amd_sink *s, const void *samples, int n)

@@ -69,6 +69,16 @@ def shard_range(total_batch, rank, world):
     return rank * n, n
 
 
+def slice_range(cells, rank, world):
+    """Frequency-sliced merge (fosphor_amd_exchange_sliced / fosphor_amd_merge_sliced): rank r owns cells
+    [r C / world, (r + 1) C / world) of the flattened [bin][x] count / histogram arrays.  ValueError when the state does not
+    split evenly (ShardedFosphor then uses the all-reduce form)."""
+    if cells % world:
+        raise ValueError("%d cells do not split into %d slices" % (cells, world))
+    per = cells // world
+    return per * rank, per * (rank + 1)
+
+
 class NativeComm:
     """The library's own RCCL communicator (fosphor_amd_comm_*).  `broadcast_id(id_bytes_or_None) -> bytes`
     hands rank 0's 128-byte id to every rank; by default torch.distributed does it (any backend)."""

@@ -271,6 +271,12 @@ int fosphor_amd_tune_placement(struct fosphor *self, const void *d_samples, int 
  * (224 tiles of 64 spectra).  -EINVAL for nonsense. */
 int fosphor_amd_plan_piece_batches(int fft_len_log, int overlap, int n_batches, int batch, long long sub_samples);
 
+/* fft_len_log = 13 only (zeros otherwise): FFT launches made in the space-sharing form (*cus work-groups, the count / merge kernels of
+ * the launch before on the CUs they leave) and in the full-chip form since the instance was made.  *cus = 0: this device never shares
+ * (its CU count is not the 256 the split is laid out for).  Which form a launch takes depends on what is still queued when it is
+ * submitted, never on the data; results are identical (tests: test_c3_space_sharing_*).  Any pointer may be NULL. */
+int fosphor_amd_share_stats(struct fosphor *self, long long *shared, long long *full, int *cus);
+
 /* Library identification: "fosphor_amd <version> gfx950". */
 const char *fosphor_amd_version(void);
 

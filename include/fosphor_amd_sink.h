@@ -117,7 +117,11 @@ class sink_runtime
 	 * reference publishes it on the block's "freq" message port, this runtime hands it to the callback (if any) and
 	 * returns it.  true when a frequency was produced. */
 	bool execute_mouse_action(mouse_action_t action, int x, int y, double *freq = nullptr);
-	void set_freq_callback(void (*cb)(double freq, void *user), void *user) { d_freq_cb = cb; d_freq_user = user; }
+	void set_freq_callback(void (*cb)(double freq, void *user), void *user)
+	{
+		std::lock_guard<std::mutex> lk(d_ui_mutex);		/* (the pair is read as one snapshot by execute_mouse_action) */
+		d_freq_cb = cb; d_freq_user = user;
+	}
 	void reshape(int width, int height);			/* cb_reshape, :291-296 */
 	/* copy of a pane layout as the worker last computed it (zoom = false: main pane) */
 	struct fosphor_render render_copy(bool zoom) const;
@@ -130,6 +134,8 @@ class sink_runtime
 	struct fosphor *core() { return d_fosphor; }
 	uint64_t frames() const { return d_frames.load(); }
 	uint64_t samples_processed() const { return d_samples.load(); }
+	/* samples taken out of the FIFO but NOT processed because the device refused them (upload / process error other than "busy") */
+	uint64_t samples_dropped() const { return d_dropped.load(); }
 	int db_ref() const { return ui_snapshot().db_ref; }
 	int db_per_div() const { return k_db_per_div[ui_snapshot().db_per_div_idx]; }
 	bool frozen() const { return d_frozen.load(); }
@@ -194,6 +200,8 @@ class sink_runtime
 	std::condition_variable d_copy_cv;
 	std::atomic<int> d_copy_gen, d_copy_pending, d_copy_sleepers;
 	std::atomic<bool> d_copy_quit;
+	std::atomic<uint64_t> d_dropped;
+	bool d_drop_reported;				/* worker only */
 
  public:
 	/* Zero-copy producer interface: a source that can write its samples anywhere (an SDR driver's receive call, a file
@@ -272,6 +280,8 @@ void *fosphor_amd_sink_write_prepare(fosphor_amd_sink *s, int want, int *got, in
 void  fosphor_amd_sink_write_commit(fosphor_amd_sink *s, int n);
 struct fosphor *fosphor_amd_sink_core(fosphor_amd_sink *s);
 void  fosphor_amd_sink_stats(fosphor_amd_sink *s, uint64_t *frames, uint64_t *samples, int *db_ref, int *db_per_div, int *frozen);
+/* samples the worker took from the FIFO and could not process (device error); 0 in a healthy run */
+uint64_t fosphor_amd_sink_dropped(fosphor_amd_sink *s);
 
 #ifdef __cplusplus
 }

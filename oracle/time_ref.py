@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from oracle_lib import RefKernels, build_oracle
 build_oracle(ref=True)

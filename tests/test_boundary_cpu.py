@@ -45,6 +45,15 @@ def test_library_exports_every_declared_symbol(amd):
     assert not unbound, "exported but unbound in _lib.py: %s" % unbound
 
 
+def test_product_library_has_no_wrong_result_switches(amd):
+    """The measurement switches that produce wrong spectra by construction (FOSPHOR_AMD_DBG_*: skip a kernel, alias chunks, drop
+    a wait, CU masks) exist only in probe builds (-DFOSPHOR_AMD_PROBES, tools/r04_ceiling_build.sh).  The shipped library must not
+    contain the name of any of them: a stray environment variable cannot change its results."""
+    blob = open(amd.LIB_PATH, "rb").read()
+    assert b"FOSPHOR_AMD_DBG" not in blob
+    assert b"FOSPHOR_AMD_TILE" in blob			# (the check can see environment names: a tuning knob that IS read, once, at init)
+
+
 def test_piece_planner_host_logic(amd):
     """fosphor_amd_plan_piece_batches: how a device-resident call is cut into sub-launches (pure host arithmetic).  Pieces are
     about sub_samples samples and equal; at fft_len_log = 13 with the streams on they are whole multiples of the unit that makes
@@ -240,3 +249,24 @@ def test_fifo_two_threads_under_thread_sanitizer(amd, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert "0 bad" in r.stdout
+
+
+def test_bench_self_launch_is_a_child_process_and_relays_failure():
+    """`python3 bench.py --gpus N` with no launcher (WORLD_SIZE unset) starts `python -m torch.distributed.run --nproc-per-node N
+    bench.py ...` as a CHILD before anything in the parent touches the GPU (bench.py imports torch only behind that branch) and
+    exits with the child's code.  Here, without a GPU, every rank fails at torch.cuda.set_device: the parent must exit non-zero
+    without a JSON line -- never zero, never a hang."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "3"], 29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[4:6] == ["--nproc-per-node", "8"]
+    assert "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node 2" in p.stderr, p.stderr[-2000:]
+    assert p.returncode != 0, "no GPU here: the launched ranks cannot have succeeded"
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -179,22 +179,51 @@ for w in (1, 2, 4, 8):
     spans = [shard_range(8192, r, w) for r in range(w)]
     assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
     assert spans[-1][0] + spans[-1][1] == 8192 and all(n % 16 == 0 for _, n in spans)
+# the frequency-sliced form (reduce-scatter + sliced merge + all-gather) over THIS world size: every rank owns one slice of the
+# flattened [bin][x] arrays, the slices tile the state exactly, and "sum everywhere, keep your slice, gather the slices" gives every
+# rank the sum of all ranks' counts (integer: order-independent, display.cl:161-177) -- for the geometries the bench shards
+from gr_fosphor_amd.dist import slice_range
+for cells in (1024 * 256, 8192 * 512, 65536 * 512):
+    spans = [slice_range(cells, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == cells and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert len(set(b - a for a, b in spans)) == 1
+cells = 1024 * 64
+gen = torch.Generator().manual_seed(1000 + rank)
+mine = torch.randint(0, 1000, (cells,), dtype=torch.int32, generator=gen)
+want = torch.zeros(cells, dtype=torch.int32)
+for r in range(world):
+    want += torch.randint(0, 1000, (cells,), dtype=torch.int32, generator=torch.Generator().manual_seed(1000 + r))
+summed = mine.clone()
+dist.all_reduce(summed, op=dist.ReduceOp.SUM)
+lo, hi = slice_range(cells, rank, world)
+own = torch.full((cells,), -1, dtype=torch.int32)
+own[lo:hi] = summed[lo:hi]                      # what a rank holds after the reduce-scatter: its slice only
+pieces = [torch.empty(hi - lo, dtype=torch.int32) for _ in range(world)]
+dist.all_gather(pieces, own[lo:hi].contiguous())
+assert torch.equal(torch.cat(pieces), want), "rank %d: gathered slices are not the sum of all ranks' counts" % rank
+try:
+    slice_range(1001, 0, world)
+    raise SystemExit("slice_range accepted a ragged split")
+except ValueError:
+    pass
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)
 '''
 
 
-@pytest.mark.parametrize("fail_on", [-1, 0, 1])
-def test_transport_agreement_world2_gloo(tmp_path, fail_on):
+@pytest.mark.parametrize("world,fail_on", [(2, -1), (2, 0), (2, 1), (8, -1), (8, 5)])
+def test_transport_agreement_gloo(tmp_path, world, fail_on):
     """bench.py --gpus N / ShardedFosphor: if the library's own RCCL communicator cannot be set up on ANY rank, EVERY rank
-    falls back to the torch transport (and a rank whose set-up had succeeded closes it again)."""
+    falls back to the torch transport (and a rank whose set-up had succeeded closes it again); the time split (shard_range) and
+    the frequency-sliced cell ranges (slice_range) tile the frame / the state at the world size under test.  World size 8 is the
+    driver's largest run: the first 8-rank contact of this logic must not be on the GPU node."""
     script = tmp_path / "worker.py"
     script.write_text(TRANSPORT_WORKER)
-    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29631 + fail_on),
-               WORLD_SIZE="2", OMP_NUM_THREADS="1", FAIL_ON=str(fail_on))
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29631 + 10 * world + fail_on),
+               WORLD_SIZE=str(world), OMP_NUM_THREADS="1", FAIL_ON=str(fail_on))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for r, p in enumerate(procs):
         try:
             out, _ = p.communicate(timeout=240)

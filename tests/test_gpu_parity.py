@@ -1503,6 +1503,132 @@ def test_c5_full_frame_properties(amd, torch_cuda, oracle_built):
         q.close()
 
 
+def test_c5_bench_launch_shape_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch):
+    """The launch shape `bench.py --config C5` times: THREE display frames of 1024 spectra x 65536 points (fp16 IQ, 512 bins, 64 Mi
+    samples each) queued back to back -- relaxed input ordering, default streams, NO finish() and no buffer read between them -- so
+    that count / scan / merge of frame f run on their own streams in the gaps of frame f + 1's FFT kernel and the intermediate sets
+    and hit-count sets are reused across frames in flight (fosphor_api.cpp run(): set / hset rotation).  Semantics: cl.c:870-968
+    applied per frame, display.cl:130-178 over each frame's 1024 spectra (the kernel is batch-generic; only the host caps it).
+    After the third frame: the last frame's hit counts equal the oracle's bit for bit, the state all three frames went into
+    (persistence histogram, live, max-hold, waterfall ring) is in tolerance, and every buffer equals, bit for bit, what the
+    single-stream form (FOSPHOR_AMD_OVERLAP=0: one kernel after the other) leaves for the same three frames."""
+    torch = torch_cuda
+    n, nb, rows, total, frames = 65536, 512, 1024, 1024, 3
+    threads = min(os.cpu_count() or 1, 64)
+    kw = dict(fft_len_log=16, n_bins=nb, wf_rows=rows, max_spectra=total, max_batches=1, iq_fp16=True)
+    g = torch.Generator(device="cuda"); g.manual_seed(1297)
+    ds = []
+    for k in range(frames):
+        d = torch.empty((total * n, 2), dtype=torch.float32, device="cuda").normal_(0.0, [0.05, 0.3, 0.01][k], generator=g)
+        if k:
+            t = torch.arange(total * n, device="cuda", dtype=torch.float32)
+            d[:, 0] += 0.1 * torch.cos(0.173 * k * t); d[:, 1] += 0.1 * torch.sin(0.173 * k * t)
+            del t
+        ds.append(d.to(torch.float16))
+        del d
+    torch.cuda.synchronize()
+    res = []
+    for overlap in ("1", "0"):
+        monkeypatch.setenv("FOSPHOR_AMD_OVERLAP", overlap)
+        f = amd.Fosphor(**kw)
+        f.set_input_ordering(False)
+        assert f.finish() >= 0					# boot fills are not part of the shape
+        for d in ds:						# all three frames in flight together, as in the timed loop
+            assert f.process_device(d, 1, total) == 0
+        assert f.finish() >= 0
+        res.append((f.hitcount.copy(), f.histogram.copy(), f.waterfall.copy(), f.spectrum.copy(), f.waterfall_pos))
+        f.close()
+    a, b = res
+    assert np.array_equal(a[0], b[0]), "hit counts differ between the three-stream and the single-stream form"
+    assert np.array_equal(canon_bits(a[1]), canon_bits(b[1])), "histogram differs between the three-stream and the single-stream form"
+    assert np.array_equal(canon_bits(a[2]), canon_bits(b[2])), "waterfall differs between the three-stream and the single-stream form"
+    assert np.array_equal(canon_bits(a[3]), canon_bits(b[3])), "spectrum differs between the three-stream and the single-stream form"
+    del b, res
+    o = Oracle(fft_len_log=16, n_bins=nb, wf_rows=rows)
+    for d in ds:
+        assert o.process(d.cpu().numpy().astype(np.float32), strict=False, nthreads=threads) == 0
+    assert a[4] == o.waterfall_pos
+    assert np.array_equal(a[0], o.hitcount.T), "last frame: hit counts differ from the oracle in %d cells" % (a[0] != o.hitcount.T).sum()
+    assert np.all(a[0].astype(np.int64).sum(0) == total)
+    assert_close(a[2], o.waterfall, "C5 bench shape: waterfall")
+    assert_close(a[3][0, :, 1], o.spectrum[0, :, 1], "C5 bench shape: live")
+    assert_close(a[3][1, :, 1], o.spectrum[1, :, 1], "C5 bench shape: max-hold")
+    assert_hist_close(a[1], o.histogram, "C5 bench shape: histogram after three frames")
+
+
+def test_c3_bench_launch_shape_vs_oracle(amd, torch_cuda, oracle_built):
+    """The launch shape `bench.py --config C3` times, against the oracle: calls of 14 batches of 4096 spectra x 8192 points, 50 %
+    overlap fused into the read (overlap_cc_impl.cc:64-79), 512 bins -- 896 tiles of 64 spectra = 4 x 224, so the FFT kernel of a
+    call that finds the previous call's count / merge kernels still queued runs on 224 CUs beside them (space sharing, DESIGN.md
+    section 8).  TWO such calls back to back, nothing read or waited for in between.  The oracle takes the same 28 batches one
+    fosphor_process at a time on the materialised stream: last batch's hit counts bit for bit, the state every batch went into in
+    tolerance; and the second call's FFT launch did take the shared form (fosphor_amd_share_stats)."""
+    torch = torch_cuda
+    n, nb, over, F, B = 8192, 512, 2, 14, 4096
+    hop = n // over
+    threads = min(os.cpu_count() or 1, 64)
+    stream_len = (F * B - 1) * hop + n
+    g = torch.Generator(device="cuda"); g.manual_seed(4321)
+    ds = []
+    for call in range(2):
+        d = torch.empty((stream_len, 2), dtype=torch.float32, device="cuda").normal_(0.0, [0.05, 0.4][call], generator=g)
+        if call:
+            t = torch.arange(stream_len, device="cuda", dtype=torch.float32)
+            d[:, 0] += 0.1 * torch.cos(0.21 * t); d[:, 1] += 0.1 * torch.sin(0.21 * t)
+            del t
+        ds.append(d)
+    torch.cuda.synchronize()
+    f = amd.Fosphor(fft_len_log=13, n_bins=nb, max_spectra=F * B, max_batches=F)
+    f.set_input_ordering(False)
+    assert f.finish() >= 0
+    for d in ds:							# back to back: the second call's FFT launch shares the chip with the first call's tail
+        assert f.process_device_overlap(d, F, B, over) == 0
+    assert f.finish() >= 0
+    shared, full, cus = f.share_stats()
+    assert shared + full == 2 and cus == 224
+    assert shared >= 1, "no FFT launch took the space-sharing form: the shape under test did not occur"
+    o = Oracle(fft_len_log=13, n_bins=nb)
+    idx = (np.arange(B)[:, None] * hop + np.arange(n)[None, :]).reshape(-1)		# overlap_cc: window t starts at sample t * hop
+    for d in ds:
+        x = d.cpu().numpy()
+        for k in range(F):
+            xb = x[k * B * hop:(k * B + B - 1) * hop + n]
+            assert o.process(xb[idx], strict=False, nthreads=threads) == 0
+        del x
+    compare_state(f, o, "C3 bench launch shape (2 calls x 14 batches x 4096 spectra, space sharing)")
+    f.close()
+
+
+def test_host_and_pinned_entry_points_interleaved(amd, torch_cuda, oracle_built):
+    """fosphor_process (the reference's entry point: host samples, staged through the instance's two pinned slots on its own
+    stream) and fosphor_amd_process_pinned / fosphor_amd_upload_pinned (upload on the copy stream, straight from the caller's pinned
+    memory) SHARE the two device staging buffers.  Alternating them on one instance must keep the sample stream in order and must
+    never let an upload land in a buffer an earlier call's FFT kernel still reads: full 1024-spectrum batches (the widest window for
+    such a race), pending uploads overtaken by a fosphor_process call, state against the oracle."""
+    import ctypes as C
+    torch = torch_cuda
+    L = amd.load()
+    f = amd.Fosphor(n_bins=256)
+    o = Oracle(n_bins=256)
+    b = 1024 * 1024
+    xs = [add_tone(gaussian_iq(b, 1500 + k, sigma=[0.05, 0.5, 0.005][k % 3]), 0.1, 0.03 * (k + 1)) for k in range(8)]
+    pins = [torch.from_numpy(x).pin_memory() for x in xs]
+    assert f.process(xs[0]) == 0						# slot 0, H2D on the instance's stream
+    assert L.fosphor_amd_process_pinned(f.h, pins[1].data_ptr(), b) == 0	# slot 1, H2D on the copy stream
+    assert L.fosphor_amd_process_pinned(f.h, pins[2].data_ptr(), b) == 0	# slot 0 again: must wait for batch 0's FFT kernel
+    assert f.process(xs[3]) == 0						# slot 1: must wait for batch 1's
+    assert L.fosphor_amd_upload_pinned(f.h, pins[4].data_ptr(), b) == 0	# two uploads pending ...
+    assert L.fosphor_amd_upload_pinned(f.h, pins[5].data_ptr(), b) == 0
+    assert f.process(xs[6]) == 0						# ... are applied first: the stream stays in order
+    assert L.fosphor_amd_pending_uploads(f.h) == 0
+    assert L.fosphor_amd_process_pinned(f.h, pins[7].data_ptr(), b) == 0
+    for x in xs:
+        assert o.process(x, nthreads=8) == 0
+    f.draw()
+    compare_state(f, o, "fosphor_process and the pinned entry points interleaved (8 batches)")
+    f.close()
+
+
 def _c5_outputs(f):
     return [canon_bits(f.waterfall), canon_bits(f.histogram), canon_bits(f.spectrum), f.hitcount.copy()]
 

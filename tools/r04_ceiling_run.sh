@@ -15,17 +15,17 @@ run() {		# label, lib ('' = product), env...
 	done
 }
 run full            ""       X=1
-run k1_only         ""       FOSPHOR_AMD_DBG_SKIP=2
-run k1_k3_only      ""       FOSPHOR_AMD_DBG_SKIP=8
-run k1_k2_only      ""       FOSPHOR_AMD_DBG_SKIP=4
+run k1_only         probes     FOSPHOR_AMD_DBG_SKIP=2
+run k1_k3_only      probes     FOSPHOR_AMD_DBG_SKIP=8
+run k1_k2_only      probes     FOSPHOR_AMD_DBG_SKIP=4
 run k1_only_nobins  nobins   FOSPHOR_AMD_DBG_SKIP=2
 run k1_only_ldsatom ldsatom  FOSPHOR_AMD_DBG_SKIP=2
 run k1_only_epi15   epi15    FOSPHOR_AMD_DBG_SKIP=2
 run full_k2noatom  k2noatom X=1
 run full_k2store   k2store  X=1
-run cumask16        ""       FOSPHOR_AMD_DBG_CUMASK=16
-run cumask32        ""       FOSPHOR_AMD_DBG_CUMASK=32
-run cumask48        ""       FOSPHOR_AMD_DBG_CUMASK=48
+run cumask16        probes     FOSPHOR_AMD_DBG_CUMASK=16
+run cumask32        probes     FOSPHOR_AMD_DBG_CUMASK=32
+run cumask48        probes     FOSPHOR_AMD_DBG_CUMASK=48
 echo "--- read_skew (K1's loads alone / loads + stores, two launches in flight)"
 ./tools/ubench/read_skew 2>&1 | tee $OUT/read_skew.txt
 echo "--- hbm_ceiling.py"
