@@ -193,36 +193,74 @@ struct fosphor
 /* Host-side tables                                                         */
 /* ------------------------------------------------------------------------ */
 
-/* Twiddles exactly as the reference forms them (fft.cl:62-68,162-166,286-297), with
- * native_sin/native_cos pinned to fosphor_portable_math.h.  Layout: one block per radix-8 pass
- * with p = 8, 64, 512, ... < N/2 ([k < p][n = 1..7]), then the final radix-2 pass ([k < N/2]).
- * For N = 1024 this is the kTw2Off / kTw3Off / kTw4Off layout of fosphor_internal.h. */
-/* N = 65536 runs this build's own radix-16 plan (oracle/fosphor_oracle.c o_dft16 / o_pass_radix16): the four constant
- * rotations W16^1,3,5,7 of dft16, then one block per twiddled pass p = 16, 256, 4096 ([k < p][j = 1..15], angle
- * -pi k / (8 p) -- the reference's expression with 16 in the place of 8). */
-static int build_twiddles16(float2 *tw, int *offsets /* [8] or NULL */)
+/* Twiddles.  N = 1024: exactly as the reference forms them (fft.cl:62-68,162-166,286-297), native_sin / native_cos pinned to
+ * fosphor_portable_math.h; one block per radix-8 pass with p = 8, 64 ([k < p][n = 1..7]), then the final radix-2 pass
+ * ([k < N/2]): the kTw2Off / kTw3Off / kTw4Off layout of fosphor_internal.h.
+ *
+ * N = 8192 and N = 65536 run this build's own plans (no reference behaviour exists at these lengths; oracle/fosphor_oracle.c,
+ * o_pass_radix8_fma / o_pass_radix16_fma / o_pass_radix2_fma, restates them): the reference's Stockham passes with the twiddles
+ * ON the radix-2 butterflies of a pass instead of on its inputs, so an item needs the twiddles of its stages -- every one of them
+ * exp(-j pi q / den) for integers q, den, formed like the reference's (one float expression, pinned sin / cos): tw_long().
+ *   N = 8192:   blocks 0-2  passes p = 8, 64, 512: [k < p][4] = w^4, w^2, w, w W8          (w = exp(-j pi k / (4 p)))
+ *               block  3    the radix-2 pass: [k < 4096] = exp(-j pi k / 4096)
+ *               block  4    the constant W8 (first pass)
+ *   N = 65536:  block  0    the constants W16, W8, W16^3 (first pass)
+ *               blocks 1-3  passes p = 16, 256, 4096: [k < p][8] = w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3
+ *                                                                                           (w = exp(-j pi k / (8 p))) */
+static float2 tw_long(int q, int den)
 {
 	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
+	const float arg = -PI_F * (float)q / (float)den;
+	return make_float2(fpm_cosf(arg), fpm_sinf(arg));
+}
+
+static int build_twiddles16(float2 *tw, int *offsets /* [8] or NULL */)
+{
 	int pos = 0, q = 0;
 	if (offsets) offsets[q] = pos;
 	q++;
-	for (int j = 1; j < 8; j += 2) {
-		const float a16 = -PI_F / 8.0f;
-		const float arg = (float)j * a16;
-		if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+	for (int m = 1; m <= 3; m++) {
+		if (tw) tw[pos] = tw_long(m, 8);
 		pos++;
 	}
 	for (int p = 16; p <= 4096; p *= 16, q++) {
 		if (offsets) offsets[q] = pos;
+		const int d = 8 * p;
 		for (int k = 0; k < p; k++) {
-			const float alpha = -PI_F * (float)k / (float)(8 * p);
-			for (int f = 1; f < 16; f++) {
-				const float arg = (float)f * alpha;
-				if (tw) tw[pos] = make_float2(fpm_cosf(arg), fpm_sinf(arg));
+			const int qs[8] = { 8 * k, 4 * k, 2 * k, 2 * k + 2 * p, k, k + p, k + 2 * p, k + 3 * p };
+			for (int f = 0; f < 8; f++) {
+				if (tw) tw[pos] = tw_long(qs[f], d);
 				pos++;
 			}
 		}
 	}
+	return pos;
+}
+
+static int build_twiddles13(float2 *tw, int *offsets /* [8] or NULL */)
+{
+	const int n = 8192;
+	int pos = 0, q = 0;
+	for (int p = 8; p < n / 2; p *= 8, q++) {
+		if (offsets) offsets[q] = pos;
+		const int d = 4 * p;
+		for (int k = 0; k < p; k++) {
+			const int qs[4] = { 4 * k, 2 * k, k, k + p };
+			for (int f = 0; f < 4; f++) {
+				if (tw) tw[pos] = tw_long(qs[f], d);
+				pos++;
+			}
+		}
+	}
+	if (offsets) offsets[q] = pos;
+	q++;
+	for (int k = 0; k < n / 2; k++) {
+		if (tw) tw[pos] = tw_long(k, n / 2);
+		pos++;
+	}
+	if (offsets) offsets[q] = pos;
+	if (tw) tw[pos] = tw_long(1, 4);
+	pos++;
 	return pos;
 }
 
@@ -233,6 +271,8 @@ static int build_twiddles(float2 *tw, int log2n, int *offsets /* [8] or NULL */)
 	int pos = 0, q = 0;
 	if (log2n == 16)
 		return build_twiddles16(tw, offsets);
+	if (log2n == 13)
+		return build_twiddles13(tw, offsets);
 	for (int p = 8; p < n / 2; p *= 8, q++) {
 		if (offsets) offsets[q] = pos;
 		for (int k = 0; k < p; k++) {

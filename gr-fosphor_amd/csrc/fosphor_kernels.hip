@@ -108,6 +108,112 @@ static __device__ __forceinline__ void dft8(v2f (&r)[8], v2f s12)
 	DFT2(r[0], r[1]); DFT2_MJ(r[2], r[3]); DFT2(r[4], r[5]); DFT2_MJ(r[6], r[7]);
 }
 
+/* ------------------------------------------------------------------------ */
+/* The long plans (N = 8192, 65536): twiddles on the butterflies, fused multiply-adds */
+/* ------------------------------------------------------------------------ */
+/* No reference behaviour exists at these lengths; the plan is this build's and the oracle restates it operation for operation
+ * (oracle/fosphor_oracle.c: o_bf, o_bf_mj, o_bf_win, o_pass_radix8_fma, o_pass_radix16_fma, o_pass_radix2_fma -- the derivation is
+ * written there).  A radix-R pass is log2 R radix-2 stages in decimation-in-time form, every butterfly
+ *      a' = a + T b  (two v_pk_fma_f32)      b' = 2 a - a'  (one)
+ * with T the twiddle of its stage and position: 36 packed operations per 8 points and pass instead of 49 (21 for seven complex
+ * products + 28 for dft8), 96 per 16 points instead of 133, and 4 / 8 twiddles per item instead of 7 / 15.  Every operation is one
+ * IEEE operation here and one fmaf / add / multiply there. */
+
+/* o_bf: u = (a.x - b.y T.y, a.y + b.x T.y);  a' = (u.x + b.x T.x, u.y + b.y T.x);  b' = 2 a - a' */
+static __device__ __forceinline__ void bf(v2f &a, v2f &b, v2f t, v2f two)
+{
+	v2f u, pa, nb;
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(b), "v"(t), "v"(a));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa) : "v"(b), "v"(t), "v"(u));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
+	a = pa; b = nb;
+}
+/* o_bf_mj (T := -j T): u = (a.x + b.x T.y, a.y + b.y T.y);  a' = (u.x + b.y T.x, u.y - b.x T.x);  b' = 2 a - a' */
+static __device__ __forceinline__ void bf_mj(v2f &a, v2f &b, v2f t, v2f two)
+{
+	v2f u, pa, nb;
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(b), "v"(t), "v"(a));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(pa) : "v"(b), "v"(t), "v"(u));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
+	a = pa; b = nb;
+}
+/* o_bf_win, stage A of the first pass: m = a wab.x;  a' = fma(b, wab.y, m);  b' = fma(-b, wab.y, m)   (wab = the two window taps) */
+static __device__ __forceinline__ void bf_win(v2f &a, v2f &b, v2f wab)
+{
+	v2f m, pa, nb;
+	asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(wab));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(pa) : "v"(b), "v"(wab), "v"(m));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(nb) : "v"(b), "v"(wab), "v"(m));
+	a = pa; b = nb;
+}
+
+/* o_pass_radix8_fma, p > 1: t4 = w^4, t2 = w^2, t1 = w, t1w = w W8.  X[m] is left in r[bitrev3(m)] like dft8 leaves it. */
+static __device__ __forceinline__ void pass8_fma(v2f (&r)[8], v2f t4, v2f t2, v2f t1, v2f t1w, v2f two)
+{
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		bf(r[j], r[j + 4], t4, two);
+	bf(r[0], r[2], t2, two); bf(r[1], r[3], t2, two); bf_mj(r[4], r[6], t2, two); bf_mj(r[5], r[7], t2, two);
+	bf(r[0], r[1], t1, two); bf_mj(r[2], r[3], t1, two); bf(r[4], r[5], t1w, two); bf_mj(r[6], r[7], t1w, two);
+}
+/* ... p = 1 (w = 1): the window on stage A (wab[j] = taps of r[j], r[j + 4]), plain sums where T is 1 or -j */
+static __device__ __forceinline__ void pass8_first(v2f (&r)[8], const v2f (&wab)[4], v2f w8, v2f two)
+{
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		bf_win(r[j], r[j + 4], wab[j]);
+	DFT2(r[0], r[2]); DFT2(r[1], r[3]); DFT2_MJ(r[4], r[6]); DFT2_MJ(r[5], r[7]);
+	DFT2(r[0], r[1]); DFT2_MJ(r[2], r[3]); bf(r[4], r[5], w8, two); bf_mj(r[6], r[7], w8, two);
+}
+
+/* o_pass_radix16_fma, p > 1, in two halves (the 65536-point kernel runs other work between them):
+ * stages A, B: t8 = w^8, t4 = w^4;  stages C, D: t2 = w^2, t2w = w^2 W8, t1 = w, t1a = w W16, t1b = w W8, t1c = w W16^3.
+ * X[m] is left in r[bitrev4(m)] (R16_PERM). */
+static __device__ __forceinline__ void pass16_ab(v2f (&r)[16], v2f t8, v2f t4, v2f two)
+{
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		bf(r[j], r[j + 8], t8, two);
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		bf(r[j], r[j + 4], t4, two);
+		bf_mj(r[8 + j], r[12 + j], t4, two);
+	}
+}
+static __device__ __forceinline__ void pass16_cd(v2f (&r)[16], v2f t2, v2f t2w, v2f t1, v2f t1a, v2f t1b, v2f t1c, v2f two)
+{
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		bf(r[j], r[j + 2], t2, two);
+		bf_mj(r[4 + j], r[6 + j], t2, two);
+		bf(r[8 + j], r[10 + j], t2w, two);
+		bf_mj(r[12 + j], r[14 + j], t2w, two);
+	}
+	bf(r[0], r[1], t1, two);   bf_mj(r[2], r[3], t1, two);    bf(r[4], r[5], t1b, two);   bf_mj(r[6], r[7], t1b, two);
+	bf(r[8], r[9], t1a, two);  bf_mj(r[10], r[11], t1a, two); bf(r[12], r[13], t1c, two); bf_mj(r[14], r[15], t1c, two);
+}
+/* ... p = 1: the window on stage A (wab[j] = taps of r[j], r[j + 8]); w16 = W16, w8 = W8, w163 = W16^3 */
+static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wab)[8], v2f w16, v2f w8, v2f w163, v2f two)
+{
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		bf_win(r[j], r[j + 8], wab[j]);
+#pragma unroll
+	for (int j = 0; j < 4; j++) {
+		DFT2(r[j], r[j + 4]);
+		DFT2_MJ(r[8 + j], r[12 + j]);
+	}
+#pragma unroll
+	for (int j = 0; j < 2; j++) {
+		DFT2(r[j], r[j + 2]);
+		DFT2_MJ(r[4 + j], r[6 + j]);
+		bf(r[8 + j], r[10 + j], w8, two);
+		bf_mj(r[12 + j], r[14 + j], w8, two);
+	}
+	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);           bf(r[4], r[5], w8, two);     bf_mj(r[6], r[7], w8, two);
+	bf(r[8], r[9], w16, two);  bf_mj(r[10], r[11], w16, two); bf(r[12], r[13], w163, two); bf_mj(r[14], r[15], w163, two);
+}
+
 /* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
 static __device__ __forceinline__ v2f mul_bcast_lo(v2f x, v2f w)
 {
@@ -960,9 +1066,11 @@ void k1big_fft_bin(const K1Params p)
 
 	const int i = threadIdx.x;
 	const int ntiles = p.total / p.tile;
-	/* the whole twiddle table (8184 entries = 64 KiB at N = 8192) sits behind the exchange slab in LDS: read
-	 * from global memory it was 21 B per sample of L2 traffic, against 8 B per sample of IQ */
-	constexpr int TWLEN = ((N / 2 - 8) / 7) * 7 + N / 2;	/* (8 + 64 + ... + N/16) * 7 + N/2 */
+	/* the whole twiddle table sits behind the exchange slab in LDS: read from global memory it was 21 B per sample of L2 traffic,
+	 * against 8 B per sample of IQ.  N = 1024: the reference's layout, 7 per item and pass; N = 8192 (the long plan, see bf()):
+	 * 4 per item and pass, the radix-2 pass's, the constant W8 */
+	constexpr bool LONG = (LOG2N != 10);
+	constexpr int TWLEN = LONG ? ((N / 2 - 8) / 7) * 4 + N / 2 + 1 : ((N / 2 - 8) / 7) * 7 + N / 2;	/* (8 + 64 + ... + N/16) * (4 | 7) + N/2 (+ 1) */
 	v2f *tws = buf + N;
 	float *wins = reinterpret_cast<float *>(tws + TWLEN);	/* and the window behind it: 160 KiB in all at N = 8192 */
 	for (int k = i; k < TWLEN; k += T)
@@ -972,6 +1080,7 @@ void k1big_fft_bin(const K1Params p)
 	__syncthreads();
 	const v2f *twg = tws;
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const v2f two = { 2.0f, 2.0f };
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
 	const float top = (float)(bk.nb - 1);
@@ -993,12 +1102,16 @@ void k1big_fft_bin(const K1Params p)
 			const float2 *src = p.iq + (size_t)t * p.hop;
 			v2f r[8];
 
-			/* window (fft.cl:415-417) */
+			/* window (fft.cl:415-417); the long plan folds it into the first pass */
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
 				const v2f xv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + i + T * j));
-				const float wv = wins[i + T * j];
-				r[j] = v2f{ xv.x * wv, xv.y * wv };
+				if (LONG) {
+					r[j] = xv;
+				} else {
+					const float wv = wins[i + T * j];
+					r[j] = v2f{ xv.x * wv, xv.y * wv };
+				}
 			}
 
 			/* radix-8 passes p = 1, 8, 64, ... (fft.cl:278-350) */
@@ -1006,13 +1119,26 @@ void k1big_fft_bin(const K1Params p)
 #pragma unroll
 			for (int q8 = 0; q8 < NP8; q8++) {
 				const int k = i & (pp - 1);
-				if (q8 > 0) {
-					const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
+				if (LONG) {
+					if (q8 == 0) {
+						v2f wab[4];
 #pragma unroll
-					for (int j = 1; j < 8; j++)
-						r[j] = c_mul(r[j], tw[j - 1]);
+						for (int j = 0; j < 4; j++)
+							wab[j] = v2f{ wins[i + T * j], wins[i + T * (j + 4)] };
+						pass8_first(r, wab, twg[p.tw_off[NP8]], two);
+					} else {
+						const v2f *tw = twg + p.tw_off[q8 - 1] + k * 4;
+						pass8_fma(r, tw[0], tw[1], tw[2], tw[3], two);
+					}
+				} else {
+					if (q8 > 0) {
+						const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
+#pragma unroll
+						for (int j = 1; j < 8; j++)
+							r[j] = c_mul(r[j], tw[j - 1]);
+					}
+					dft8(r, s12);
 				}
-				dft8(r, s12);
 				const int j0 = ((i - k) << 3) + k;
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
@@ -1034,8 +1160,12 @@ void k1big_fft_bin(const K1Params p)
 				const int jb = i + T * c;
 				v2f a = buf[swz(jb)];
 				v2f b = buf[swz(jb + N / 2)];
-				b = c_mul(b, twg[p.tw_off[NP8 - 1] + jb]);
-				DFT2(a, b);
+				if (LONG) {
+					bf(a, b, twg[p.tw_off[NP8 - 1] + jb], two);		/* o_pass_radix2_fma */
+				} else {
+					b = c_mul(b, twg[p.tw_off[NP8 - 1] + jb]);
+					DFT2(a, b);
+				}
 				x[c] = a;		/* column jb */
 				x[c + 4] = b;		/* column jb + N/2 */
 			}
@@ -1148,28 +1278,34 @@ void k1w_fft_bin(const K1Params p)
 	const int th = threadIdx.x;
 	const int ntiles = p.total / p.tile;
 	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const v2f two = { 2.0f, 2.0f };
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
 	const float top = (float)(bk.nb - 1);
 
-	/* ---- per-thread constants ------------------------------------------------ */
-	v2f win[8];			/* taps of elements (2 th, 2 th + 1) + 1024 j */
-	v2f tw8[7], tw64[7], tw512[7];	/* k = th & 7, th & 63, th (both items of a pair) */
+	/* ---- per-thread constants (the long plan, see bf(): 4 twiddles per item and pass) -------- */
+	v2f wab[2][4];			/* wab[v][j]: taps of elements 2 th + v + 1024 j and + 1024 (j + 4): the pair of a first-pass stage-A butterfly */
+	v2f tw8[4], tw64[4], tw512[4];	/* w^4, w^2, w, w W8 for k = th & 7, th & 63, th (both items of a pair) */
 	v2f twr[8];			/* radix-2 twiddles k = th + 512 c */
+	const v2f w8c = twg[p.tw_off[4]];
 #pragma unroll
-	for (int j = 0; j < 8; j++) {
-		win[j] = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * j);
-		twr[j] = twg[p.tw_off[3] + th + 512 * j];
+	for (int j = 0; j < 4; j++) {
+		const v2f lo = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * j);
+		const v2f hi = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * (j + 4));
+		wab[0][j] = v2f{ lo.x, hi.x };
+		wab[1][j] = v2f{ lo.y, hi.y };
 	}
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		twr[j] = twg[p.tw_off[3] + th + 512 * j];
 	for (int e = th; e <= p.n_bins && e < 520; e += TH)
 		thr_g[e] = p.thr[e];
 	__syncthreads();
 #pragma unroll
-	for (int n = 0; n < 7; n++) {
-		tw8[n]   = twg[p.tw_off[0] + (th & 7) * 7 + n];
-		tw64[n]  = twg[p.tw_off[1] + (th & 63) * 7 + n];
-		tw512[n] = twg[p.tw_off[2] + th * 7 + n];
+	for (int n = 0; n < 4; n++) {
+		tw8[n]   = twg[p.tw_off[0] + (th & 7) * 4 + n];
+		tw64[n]  = twg[p.tw_off[1] + (th & 63) * 4 + n];
+		tw512[n] = twg[p.tw_off[2] + th * 4 + n];
 	}
 
 	/* ---- LDS addressing (8-byte elements, phys(e) = e ^ ((e >> 3) & 15) as in the other kernels) ----
@@ -1272,11 +1408,11 @@ void k1w_fft_bin(const K1Params p)
 		v2f x[16];
 		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
 
-		/* window (fft.cl:415-417): x[2 j + v] = element 2 th + v + 1024 j */
+		/* x[2 j + v] = element 2 th + v + 1024 j (the window multiply of fft.cl:415-417 rides on the first pass) */
 #pragma unroll
 		for (int j = 0; j < 8; j++) {
-			x[2 * j]     = mul_bcast_lo(v2f{ q[j].x, q[j].y }, win[j]);
-			x[2 * j + 1] = mul_bcast_hi(v2f{ q[j].z, q[j].w }, win[j]);
+			x[2 * j]     = v2f{ q[j].x, q[j].y };
+			x[2 * j + 1] = v2f{ q[j].z, q[j].w };
 		}
 
 		/* raw IQ of the next spectrum of this tile: shared elements move down, the new ones are requested now */
@@ -1308,7 +1444,7 @@ void k1w_fft_bin(const K1Params p)
 			v2f r[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
-			dft8(r, s12);
+			pass8_first(r, wab[v], w8c, two);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
@@ -1324,10 +1460,9 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 		for (int v = 0; v < 2; v++) {
 			v2f r[8];
-			r[0] = x[v];
 #pragma unroll
-			for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw8[j - 1]);
-			dft8(r, s12);
+			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
+			pass8_fma(r, tw8[0], tw8[1], tw8[2], tw8[3], two);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
 				slab1[(st2 ^ (jj | (8 * (jj & 1)) | (16 * (jj >> 1)))) + 4096 * v] = r[R8_PERM(jj)];
@@ -1343,10 +1478,9 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 		for (int v = 0; v < 2; v++) {
 			v2f r[8];
-			r[0] = x[v];
 #pragma unroll
-			for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw64[j - 1]);
-			dft8(r, s12);
+			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
+			pass8_fma(r, tw64[0], tw64[1], tw64[2], tw64[3], two);
 #pragma unroll
 			for (int jj = 0; jj < 8; jj++)
 				slab0[(st3 ^ ((8 * jj) & 15)) + 64 * jj + 4096 * v] = r[R8_PERM(jj)];
@@ -1364,10 +1498,9 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
 				v2f r[8];
-				r[0] = x[v];
 #pragma unroll
-				for (int j = 1; j < 8; j++) r[j] = c_mul(x[v + 2 * j], tw512[j - 1]);
-				dft8(r, s12);
+				for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
+				pass8_fma(r, tw512[0], tw512[1], tw512[2], tw512[3], two);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++) y[jj + 8 * v] = r[R8_PERM(jj)];
 			}
@@ -1375,8 +1508,8 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 			for (int c = 0; c < 8; c++) {
 				v2f a = y[c];
-				v2f b = c_mul(y[c + 8], twr[c]);
-				DFT2(a, b);
+				v2f b = y[c + 8];
+				bf(a, b, twr[c], two);		/* o_pass_radix2_fma */
 				xo[c] = a;
 				xo[c + 8] = b;
 			}
@@ -1403,8 +1536,8 @@ void k1w_fft_bin(const K1Params p)
 /* K1 for N = 65536: radix-16 plan, two stages, the intermediate in the XCD's L2 */
 /* ------------------------------------------------------------------------ */
 /* No reference behaviour exists at N = 65536 (fft.cl has one length, 1024): the plan is this build's own and the oracle
- * restates it (oracle/fosphor_oracle.c, o_dft16 / o_pass_radix16): four Stockham radix-16 passes, p = 1, 16, 256, 4096,
- * 4096 virtual work-items of 16 points, with dft16 = one radix-2 stage + the reference's dft8 twice.  512 KiB per
+ * restates it (oracle/fosphor_oracle.c, o_pass_radix16_fma): four Stockham radix-16 passes, p = 1, 16, 256, 4096,
+ * 4096 virtual work-items of 16 points, a pass = four radix-2 stages with the twiddles on the butterflies (bf(), above).  512 KiB per
  * spectrum does not fit one CU's LDS, but the data flow factors into two 256-point levels:
  *
  *   stage A  passes 1-2 only mix inputs whose index is congruent mod 256: for each residue q they ARE the two passes of a
@@ -1446,44 +1579,29 @@ void k1w_fft_bin(const K1Params p)
  *     which requests no IQ, before its epilogue's stores;
  *   - the exact path's threshold table sits in LDS (ds_read has its own counter). */
 
-/* X[jj] of dft16 sits in r[bitrev4(jj)] */
+/* Loads return IN ORDER and the first stage of a radix-16 pass pairs inputs j and j + 8: requested in this order, a butterfly's two inputs
+ * arrive together (requested 0..15, the first butterfly waited for nine loads).  K1H_LOAD_ORDER=0: plain order (A/B builds). */
+#ifndef K1H_LOAD_ORDER
+#define K1H_LOAD_ORDER 1
+#endif
+#define K1H_PAIR(i) (K1H_LOAD_ORDER ? ((((i) & 1) << 3) | ((i) >> 1)) : (i))
+#ifndef K1H_SPLIT
+#define K1H_SPLIT 1			/* where the second pass of the NEXT spectrum's stage A runs (A/B builds): 0 stages A, B behind the arrival at the cluster
+					 * barrier and C, D beside the loads of the intermediate; 1 all of it beside the loads; 2 all of it behind the arrival */
+#endif
+/* K1H_TIMING=1 (probe builds only, tools/k1h_phase_timing.py): s_memtime stamps per phase of the 65536-point kernel's loop, accumulated per
+ * wave (waves 0, 3 and 7 of a work-group) into K1Params::dbg[(work-group * 3 + slot) * 16 + phase]. */
+#ifndef K1H_TIMING
+#define K1H_TIMING 0
+#endif
+#if K1H_TIMING
+#define K1H_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+		const long long _now = __builtin_readcyclecounter(); hacc[i] += _now - hprev; hprev = _now; } while (0)
+#else
+#define K1H_STAMP(i) do { } while (0)
+#endif
+/* X[jj] of a radix-16 pass sits in r[bitrev4(jj)] */
 #define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))
-
-/* o_dft16: radix-2 stage, W16^j on the odd half (full products for odd j, the reference's constant rotations for j = 2, 4,
- * 6 -- the one by -j folded into the butterfly that consumes it), then dft8 on each half */
-static __device__ __forceinline__ void dft16(v2f (&r)[16], v2f s12, const v2f (&c16)[4])
-{
-#pragma unroll
-	for (int j = 0; j < 8; j++)
-		DFT2(r[j], r[j + 8]);
-	r[9]  = c_mul(r[9], c16[0]);
-	r[10] = mul_p1q4(r[10], s12);
-	r[11] = c_mul(r[11], c16[1]);
-	/* r[12] = mul_p1q2(r[12]): folded into the first butterfly of the second dft8 */
-	r[13] = c_mul(r[13], c16[2]);
-	r[14] = mul_p3q4(r[14], s12);
-	r[15] = c_mul(r[15], c16[3]);
-	{
-		v2f a[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) a[j] = r[j];
-		dft8(a, s12);
-#pragma unroll
-		for (int j = 0; j < 8; j++) r[j] = a[j];
-	}
-	{
-		v2f b[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++) b[j] = r[8 + j];
-		/* dft8 (fft.cl:112-145) with b[4] still to be rotated by -j */
-		DFT2_MJ(b[0], b[4]); DFT2(b[1], b[5]); DFT2(b[2], b[6]); DFT2(b[3], b[7]);
-		b[5] = mul_p1q4(b[5], s12); b[7] = mul_p3q4(b[7], s12);
-		DFT2(b[0], b[2]); DFT2(b[1], b[3]); DFT2_MJ(b[4], b[6]); DFT2(b[5], b[7]);
-		DFT2(b[0], b[1]); DFT2_MJ(b[2], b[3]); DFT2(b[4], b[5]); DFT2_MJ(b[6], b[7]);
-#pragma unroll
-		for (int j = 0; j < 8; j++) r[8 + j] = b[j];
-	}
-}
 
 /* Buffer addressing for the 65536-point kernel: every global access of its loop is `scalar base (descriptor) + ONE 32-bit per-lane
  * offset + a scalar offset` -- buffer_load / buffer_store ... offen -- where the per-lane offset is fixed for the kernel's lifetime and
@@ -1519,7 +1637,8 @@ constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 1
 constexpr int kXLen   = 8 * kXaWave > kXbLen ? 8 * kXaWave : kXbLen;	/* the two exchanges share one region (a barrier separates their uses) */
 constexpr int kInLen  = 256 * 32;		/* staged fp16 input of one spectrum: [row m 256][residue 32] dwords, 16-byte pieces permuted inside a row */
 constexpr int kThrMax  = 520;			/* exact-bin thresholds kept in LDS (n_bins + 1 <= 513 doubles) */
-constexpr size_t kK1hLds = ((size_t)kXLen + 16 * 15 + 32 * 15) * sizeof(float2) + (size_t)2 * kInLen * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
+constexpr int kTwRow = 9;			/* LDS twiddle tables: 8 twiddles per row, rows padded to 9 entries (72 B: 16 / 32 rows fall into different banks) */
+constexpr size_t kK1hLds = ((size_t)kXLen + 16 * kTwRow + 32 * kTwRow) * sizeof(float2) + (size_t)2 * kInLen * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
 						/* (exchange, two twiddle tables, staged input + window taps in the same layout, thresholds) */
 
 template <bool HALF, bool WRITE_FFT>
@@ -1533,9 +1652,9 @@ void k1h_fused(const K1Params p)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	v2f *xa_all = reinterpret_cast<v2f *>(smem_raw);		/* stage A: one private exchange region per wave ... */
 	v2f *xb = xa_all;						/* ... stage B: the work-group's exchange array, in the same memory */
-	v2f *twa_t = xa_all + kXLen;					/* pass-2 twiddles [k2 16][15] */
-	v2f *tw3_t = twa_t + 16 * 15;					/* pass-3 twiddles of this member's 32 offsets [32][15] */
-	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + 32 * 15);	/* fp16 IQ of the next two spectra (two buffers of kInLen dwords) */
+	v2f *twa_t = xa_all + kXLen;					/* pass-2 twiddles [k2 16][8 of kTwRow] */
+	v2f *tw3_t = twa_t + 16 * kTwRow;				/* pass-3 twiddles of this member's 32 offsets [32][8 of kTwRow] */
+	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + 32 * kTwRow);	/* fp16 IQ of the next two spectra (two buffers of kInLen dwords) */
 	/* the exact-bin thresholds: the rare path that consults them must not wait for the loads and stores in flight (LDS reads have
 	 * their own counter) */
 	typedef const __attribute__((address_space(3))) double *lds_cdp;
@@ -1613,7 +1732,7 @@ void k1h_fused(const K1Params p)
 	const int lane = tid & 63;
 	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
+	const v2f two = { 2.0f, 2.0f };
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
 	const float top = (float)(bk.nb - 1);
@@ -1635,26 +1754,23 @@ void k1h_fused(const K1Params p)
 	const unsigned wld = 8u * (unsigned)(ib * 32 + (kkl ^ ((ib & 1) << 4)));		/* stage-B loads */
 	const __amdgpu_buffer_rsrc_t rs_wf = make_rsrc(p.wf), rs_part = make_rsrc(p.partial);
 
-	v2f c16[4];
+	const v2f w16c = twg[p.tw_off[0]], w8c = twg[p.tw_off[0] + 1], w163c = twg[p.tw_off[0] + 2];	/* W16, W8, W16^3: the first pass */
+	v2f wab[HALF ? 8 : 1];						/* wab[j]: the window taps of this thread's pass-1 inputs j and j + 8, the pair of
+									 * a stage-A butterfly (fp32 IQ, not a BASELINE configuration at this length: read
+									 * where they are used -- its 32 staging registers leave no room for them) */
 #pragma unroll
-	for (int i = 0; i < 4; i++)
-		c16[i] = twg[p.tw_off[0] + i];
-	float wina[HALF ? 16 : 1];					/* the 16 window taps of this thread's pass-1 item (fp32 IQ, not a BASELINE
-									 * configuration at this length: read where they are used -- its 32 staging
-									 * registers leave no room for them) */
+	for (int j = 0; j < (HALF ? 8 : 1); j++)
+		wab[j] = v2f{ p.win[qa + 256 * (ia + 16 * j)], p.win[qa + 256 * (ia + 16 * (j + 8))] };
+	v2f tw4[8];							/* pass 4: w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3 of k = kk + 256 ib */
 #pragma unroll
-	for (int j = 0; j < (HALF ? 16 : 1); j++)
-		wina[j] = p.win[qa + 256 * (ia + 16 * j)];
-	v2f tw4[15];
-#pragma unroll
-	for (int j = 0; j < 15; j++)
-		tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 15 + j];
+	for (int j = 0; j < 8; j++)
+		tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 8 + j];
 	for (int e = tid; e <= p.n_bins && e < kThrMax; e += 512)
 		thr_g[e] = p.thr[e];
-	for (int e = tid; e < 16 * 15; e += 512)
-		twa_t[e] = twg[p.tw_off[1] + e];
-	for (int e = tid; e < 32 * 15; e += 512)
-		tw3_t[e] = twg[p.tw_off[2] + (32 * member) * 15 + e];
+	for (int e = tid; e < 16 * 8; e += 512)
+		twa_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[1] + e];
+	for (int e = tid; e < 32 * 8; e += 512)
+		tw3_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[2] + (32 * member) * 8 + e];
 	__syncthreads();
 
 	v2f *xa = xa_all + wv * kXaWave;
@@ -1705,7 +1821,8 @@ void k1h_fused(const K1Params p)
 	auto stage_a1 = [&](int t, int buf) {
 		const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.iq + (size_t)t * p.hop);
 #pragma unroll
-		for (int j = 0; j < 16; j++) {
+		for (int jo = 0; jo < 16; jo++) {
+			const int j = K1H_PAIR(jo);
 			v2f xv;
 			if (HALF) {
 				const uint32_t raw = inb[buf * kInLen + in_rd + 512 * j];
@@ -1716,10 +1833,18 @@ void k1h_fused(const K1Params p)
 			} else {
 				xv = bld_v2f<kAuxNT>(rs_f, 8u * (unsigned)(qa + 256 * ia), 32768u * j);
 			}
-			const float wj = HALF ? wina[HALF ? j : 0] : p.win[qa + 256 * (ia + 16 * j)];
-			ra[j] = v2f{ xv.x * wj, xv.y * wj };			/* window, fft.cl:415-417 */
+			ra[j] = xv;
 		}
-		dft16(ra, s12, c16);
+		/* first pass (p = 1), the window of fft.cl:415-417 on its stage-A butterflies */
+		if constexpr (HALF) {
+			pass16_first(ra, wab, w16c, w8c, w163c, two);
+		} else {
+			v2f wl[8];
+#pragma unroll
+			for (int j = 0; j < 8; j++)
+				wl[j] = v2f{ p.win[qa + 256 * (ia + 16 * j)], p.win[qa + 256 * (ia + 16 * (j + 8))] };
+			pass16_first(ra, wl, w16c, w8c, w163c, two);
+		}
 	};
 	/* ... and the 16 x 16 transpose inside the wave that follows it */
 	auto stage_a1x = [&]() {
@@ -1728,18 +1853,20 @@ void k1h_fused(const K1Params p)
 			xa[ea_w + 17 * jj] = ra[R16_PERM(jj)];
 		wave_lds_sync();
 #pragma unroll
-		for (int j = 0; j < 16; j++)
-			ra[j] = xa[ea_r + j];
+		for (int jo = 0; jo < 16; jo++)
+			ra[K1H_PAIR(jo)] = xa[ea_r + K1H_PAIR(jo)];
 		wave_lds_sync();
 	};
 	/* pass 2, p = 16, k = ia */
-	auto stage_a2 = [&]() {
-#pragma unroll
-		for (int j = 1; j < 16; j++)
-			ra[j] = c_mul(ra[j], twa_t[ia * 15 + j - 1]);
-		dft16(ra, s12, c16);
-	};
+	const v2f *twa_r = twa_t + ia * kTwRow;
+	auto stage_a2_ab = [&]() { pass16_ab(ra, twa_r[0], twa_r[1], two); };
+	auto stage_a2_cd = [&]() { pass16_cd(ra, twa_r[2], twa_r[3], twa_r[4], twa_r[5], twa_r[6], twa_r[7], two); };
+	auto stage_a2 = [&]() { stage_a2_ab(); stage_a2_cd(); };
 
+#if K1H_TIMING
+	long long hacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	long long hprev = __builtin_readcyclecounter();
+#endif
 	uint32_t *bins_lo = p.bins;					/* [total / 4][N] dwords: 4 spectra x low 8 bits */
 	uint32_t *bins_hi = p.bins + (size_t)(p.total >> 2) * N;	/* [total / tile][N] dwords: bit u = 9th bit of the tile's spectrum u */
 
@@ -1792,9 +1919,11 @@ void k1h_fused(const K1Params p)
 		const int t = t0 + u;
 		const bool more = (u + 1 < p.tile);
 
+		K1H_STAMP(0);		/* loop overhead, tile claim (first spectrum of a tile) */
 		/* (every member has read the previous spectrum out of the intermediate: the last wave looked before its epilogue)
 		 * every read of the stage-B exchange array is done -- stage A writes the same memory */
 		wg_barrier_lds();
+		K1H_STAMP(1);		/* top barrier: waiting for the work-group's slowest wave */
 		if (!(PROBE_K1H(p) & 8)) {
 			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
 			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
@@ -1805,18 +1934,24 @@ void k1h_fused(const K1Params p)
 		}
 		if (more)
 			stage_a1(t + 1, (u + 1) & 1);			/* (while the stores travel) */
+		K1H_STAMP(2);		/* intermediate stores issued + first pass of the next spectrum */
 		/* this wave's blocks are in the L2 (and the input rows it requested most of an iteration ago in LDS) */
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		K1H_STAMP(3);		/* waiting for the stores' acknowledgements (and the IQ requested an iteration ago) */
 		wg_barrier_lds();
 		if (tid == 0)
 			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		K1H_STAMP(4);		/* barrier + arrival */
 		if (more) {
-			stage_a1x();					/* (while the arrivals travel) */
-#pragma unroll
-			for (int j = 1; j < 16; j++)
-				ra[j] = c_mul(ra[j], twa_t[ia * 15 + j - 1]);
+			if (K1H_SPLIT != 3)
+				stage_a1x();				/* (while the arrivals travel) */
+			if (K1H_SPLIT == 0)
+				stage_a2_ab();				/* second pass, stages A and B (C and D: beside the loads below) */
+			else if (K1H_SPLIT == 2)
+				stage_a2();
 		}
 
+		K1H_STAMP(5);		/* transpose (+ what of the second pass runs here) */
 		if (tid == 0 && !(PROBE_K1H(p) & 1)) {
 			uint32_t spins = 0;
 			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0) {
@@ -1826,47 +1961,63 @@ void k1h_fused(const K1Params p)
 		}
 		wg_barrier_lds();
 		asm volatile("" ::: "memory");
+		K1H_STAMP(6);		/* cluster barrier: poll + work-group barrier */
 
 		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
 		v2f r[16];
 		if (!(PROBE_K1H(p) & 8)) {
 			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
 #pragma unroll
-			for (int j = 0; j < 16; j++)
-				r[j] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * j);
+			for (int jo = 0; jo < 16; jo++)
+				r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * K1H_PAIR(jo));
 		} else {
 #pragma unroll
 			for (int j = 0; j < 16; j++)
 				r[j] = ra[j];
 		}
-		if (more)
-			dft16(ra, s12, c16);				/* (while the loads travel) */
-#pragma unroll
-		for (int j = 1; j < 16; j++)					/* pass 3, p = 256, k = kk */
-			r[j] = c_mul(r[j], tw3_t[kkl * 15 + j - 1]);
+		if (more) {						/* (while the loads travel) */
+			if (K1H_SPLIT == 0)
+				stage_a2_cd();
+			else if (K1H_SPLIT == 1)
+				stage_a2();
+			else if (K1H_SPLIT == 3) {
+				stage_a1x();
+				stage_a2();
+			}
+		}
+		K1H_STAMP(7);		/* loads of the intermediate issued + second pass of the next spectrum */
+		const v2f *tw3_r = tw3_t + kkl * kTwRow;			/* pass 3, p = 256, k = kk */
+		pass16_ab(r, tw3_r[0], tw3_r[1], two);
+#if K1H_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		K1H_STAMP(8);		/* third pass, stages A and B: includes the wait for the loads */
 		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (two barriers ago); it is
 		 * waited for by the `vmcnt(0)` of the NEXT iteration.  Requested only now that the loads of the intermediate have been used:
 		 * loads return in order, and these come from HBM */
 		if (u + 3 < p.tile)
 			fetch_iq(t + 3, (u + 1) & 1);
-		dft16(r, s12, c16);
+		pass16_cd(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
 #pragma unroll
 		for (int jj = 0; jj < 16; jj++)
 			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
+		K1H_STAMP(9);		/* IQ request + third pass, stages C and D + exchange stores */
 		wg_barrier_lds();
 		if (tid == 0)							/* everybody's loads of the intermediate have landed */
 			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		done++;
+		K1H_STAMP(10);		/* exchange barrier */
 #pragma unroll
-		for (int j = 0; j < 16; j++)
-			r[j] = xb[eb_r + j];
-#pragma unroll
-		for (int j = 1; j < 16; j++)					/* pass 4, p = 4096, k = kk + 256 ib */
-			r[j] = c_mul(r[j], tw4[j - 1]);
-		dft16(r, s12, c16);
+		for (int jo = 0; jo < 16; jo++)
+			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
+		pass16_ab(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
+		pass16_cd(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
 
+		K1H_STAMP(11);		/* exchange loads + fourth pass */
 		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
-		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them */
+		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them.  (Round 5, K1H_TIMING build: the
+		 * ~2000 cycles this wave spends here per spectrum are the spread between the cluster's members, not a round trip -- requesting
+		 * the counter one pass EARLIER and looking at the answer here returned "not yet" and cost 50 us per frame on top.) */
 		if (tid == 448 && !(PROBE_K1H(p) & 1)) {
 			uint32_t spins = 0;
 			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
@@ -1875,6 +2026,7 @@ void k1h_fused(const K1Params p)
 			}
 		}
 
+		K1H_STAMP(12);		/* "everyone has read the intermediate" poll (last wave only) */
 		if (WRITE_FFT) {
 #pragma unroll
 			for (int c = 0; c < 16; c++)
@@ -1934,6 +2086,7 @@ void k1h_fused(const K1Params p)
 				plo[c] = 0;
 			}
 		}
+		K1H_STAMP(13);		/* epilogue */
 	}
 	if (!(PROBE_K1H(p) & 4)) {
 		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
@@ -1946,6 +2099,13 @@ void k1h_fused(const K1Params p)
 		bst_v2f<0>(v2f{ live[c] * F_HALF_LOG10_2, (vmax[c] == vmax_init) ? -1000.0f : vmax[c] * F_HALF_LOG10_2 },
 		           rs_part, 8u * ucol0, (uint32_t)tile * (uint32_t)(N * 8) + 32768u * c);
 	}
+#if K1H_TIMING
+	if (p.dbg && lane == 0 && (wv == 0 || wv == 3 || wv == 7)) {
+		const int slot = (wv == 0) ? 0 : (wv == 3) ? 1 : 2;
+		for (int i = 0; i < 16; i++)
+			p.dbg[((size_t)blockIdx.x * 3 + slot) * 16 + i] = hacc[i];
+	}
+#endif
 	leave();
 }
 
@@ -1988,7 +2148,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		if (p.log2n == 10) {
 			/* N = 1024 with 16-bit bin indices (more than 256 bins): the general kernel at 128 threads per spectrum */
 			constexpr int N = 1024;
-			constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;
+			constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;		/* exchange slab + the reference's twiddles + window */
 			const int blocks = tiles < 4096 ? tiles : 4096;
 			if (p.fft_out)
 				hipLaunchKernelGGL((k1big_fft_bin<10, true>), dim3(blocks), dim3(N / 8), lds, s, p);
@@ -2023,7 +2183,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 			return hipGetLastError();
 		}
 		constexpr int N = 8192;
-		constexpr int lds = (N + ((N / 2 - 8) / 7) * 7 + N / 2) * 8 + N * 4;	/* exchange slab + twiddle table + window: 160 KiB */
+		constexpr int lds = (N + ((N / 2 - 8) / 7) * 4 + N / 2 + 1) * 8 + N * 4;	/* exchange slab + the long plan's twiddle table + window */
 		const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
 		int blocks = tiles < all_cus ? tiles : all_cus;		/* one work-group (16 waves, 128 VGPRs) per CU */
 		if (!attr_set) {
@@ -2327,8 +2487,11 @@ void k2_count(const K2Params p)
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
 	const size_t lds = (size_t)p.n_bins * 32 * sizeof(uint32_t);
+#ifndef K2_IF16
+#define K2_IF16 4		/* index loads in flight per thread, 16-bit / 9-bit index geometries (A/B builds) */
+#endif
 	if (p.bins16 || p.bins9)
-		hipLaunchKernelGGL((k2_count<16, 4>), dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
+		hipLaunchKernelGGL((k2_count<16, K2_IF16>), dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
 	else if (p.chunk > 1024)
 		hipLaunchKernelGGL((k2_count<4, 4>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	else

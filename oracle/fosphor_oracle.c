@@ -140,63 +140,186 @@ static void o_pass_radix4(const cf *src, cf *dst, int n, int p)
 	}
 }
 
-/* ---- the radix-16 plan of N = 65536 (and 8192) --------------------------------------------------------------
- * The reference has one FFT length, 1024 (fft.cl:397-466), and no butterfly wider than 8.  For the lengths BASELINE
- * configs C3 / C5 name, no reference behaviour exists; the plan below is THIS BUILD'S OWN CHOICE,
- * made for the GPU's memory hierarchy -- two radix-16 passes are a 256-point transform that one wavefront does on its
- * own -- and restated here operation for operation so that the GPU kernels can be checked bit for bit.  It is built
- * from the reference's pieces only: dft2 / dft8 (fft.cl:86-145), the constant rotations mul_p1q2 / p1q4 / p3q4
- * (fft.cl:77-82), twiddle() with the reference's expression for the angle (fft.cl:61-69, 286-297), and the Stockham
- * indexing of fft.cl:278-350 with 16 in the place of 8.
+/* ---- the plans of the long lengths: N = 8192 (BASELINE C3) and N = 65536 (C5) -----------------------------------
+ * The reference has ONE FFT length, 1024 (fft.cl:397-466), and no reference behaviour exists for the lengths BASELINE
+ * configs C3 / C5 name.  The plans below are THIS BUILD'S OWN CHOICE, restated here operation for
+ * operation so that the GPU kernels can be checked bit for bit.  They keep the reference's data flow -- Stockham passes with
+ * the indexing of fft.cl:278-350 (radix 8, p = 1, 8, 64, 512, then the radix-2 pass of fft.cl:428-458 at N = 8192; the same
+ * with 16 in the place of 8, p = 1, 16, 256, 4096, at N = 65536), twiddle angles from the reference's expression
+ * -pi k / ((R/2) p) (fft.cl:286-297) through the pinned sin / cos -- and change the ARITHMETIC INSIDE A PASS to what a
+ * fused-multiply-add machine does best: the radix-R butterfly is log2(R) radix-2 stages in decimation-in-time form whose
+ * twiddles sit ON the butterflies,
+ *         a' = a + T b        two fused multiply-adds per component pair:  u = fma(b.yx, (-T.y, T.y), a);  a' = fma(b, T.x, u)
+ *         b' = 2 a - a'       one:                                          b' = fma(2, a, -a')
+ * instead of "multiply every input by its twiddle (fft.cl:37-46: 2 mul + 1 add/sub per product), then an untwiddled dft8
+ * (fft.cl:112-145)".  Per radix-8 pass that is 12 butterflies x 3 packed operations = 36 per 8 points against 49, with 4
+ * twiddles per item (w^4, w^2, w, w W8) instead of 7; per radix-16 pass 96 per 16 points against 133, 8 twiddles against 15.
+ * Every operation is ONE IEEE fused multiply-add (fmaf here, v_pk_fma_f32 there) or one add / multiply: bit-reproducible.
  *
- * dft16: decimation in frequency, one radix-2 stage in front of two dft8:
- *     a[j] = r[j] + r[j + 8],  b[j] = (r[j] - r[j + 8]) * W16^j,  j < 8;   X[2m] = DFT8(a)[m],  X[2m + 1] = DFT8(b)[m]
- * W16^j = twiddle(., j, -pi/8) for odd j (full complex products with the pinned sin / cos), the reference's constant
- * rotations for j = 2, 4, 6.  Like o_dft8 it leaves X[jj] in r[bitrev4(jj)]. */
-static inline void o_dft16(cf *r)
+ * Derivation (R = 16; R = 8 drops the first stage): X[m] = sum_j W16^(j m) w^j r[j].  Splitting j = j' + 8 j1:
+ *   X[m] = sum_{j' < 8} W16^(j' m) w^j' ( r[j'] + (-1)^m0 w^8 r[j' + 8] ),  m0 = m & 1        -> stage A, T = w^8
+ * and again with distances 4, 2, 1: the twiddle of a stage is w^(R / 2^s) times the power of W16 its position implies,
+ *   B: T = w^4 (-j)^m0      C: T = w^2 W8^m0 (-j)^m1      D: T = w W16^m0 W8^m1 (-j)^m2
+ * (the '+' output stays where a was, the '-' output goes where b was), so that X[m0 + 2 m1 + 4 m2 + 8 m3] ends in register
+ * 8 m0 + 4 m1 + 2 m2 + m3 = bitrev4(m), the order the reference's dft8 leaves its results in as well (fft.cl:321-328).
+ * A factor -j is a swap of the components with one sign change and costs nothing (o_bf_mj).
+ * The window multiply of fft.cl:415-417 is folded into stage A of the first pass (p = 1, w = 1):
+ *   m = a win_a;  a' = fma(b, win_b, m);  b' = fma(b, -win_b, m). */
+
+/* exp(-j pi q / den) through the pinned sin / cos: every twiddle of the long plans */
+static inline cf o_tw(int q, int den)
 {
-	const float a16 = -ORACLE_PI_F / 8.0f;
-	int j;
-	for (j = 0; j < 8; j++)
-		o_dft2(&r[j], &r[j + 8]);
-	r[9]  = o_twiddle(r[9], 1, a16);
-	r[10] = o_mul_p1q4(r[10]);
-	r[11] = o_twiddle(r[11], 3, a16);
-	r[12] = o_mul_p1q2(r[12]);
-	r[13] = o_twiddle(r[13], 5, a16);
-	r[14] = o_mul_p3q4(r[14]);
-	r[15] = o_twiddle(r[15], 7, a16);
-	o_dft8(r);
-	o_dft8(r + 8);
+	cf w;
+	float arg = -ORACLE_PI_F * (float)q / (float)den;
+	w.x = fpm_cosf(arg);
+	w.y = fpm_sinf(arg);
+	return w;
 }
 
-/* One Stockham radix-16 pass: fft.cl:278-350 with t = N/16 work-items of 16 points, angle -pi k / (8 p). */
-static void o_pass_radix16(const cf *src, cf *dst, int n, int p, int tw)
+/* a' = a + T b, b' = 2 a - a' */
+static inline void o_bf(cf *a, cf *b, cf t)
+{
+	float ux = fmaf(-b->y, t.y, a->x);
+	float uy = fmaf( b->x, t.y, a->y);
+	float px = fmaf( b->x, t.x, ux);
+	float py = fmaf( b->y, t.x, uy);
+	b->x = fmaf(a->x, 2.0f, -px);
+	b->y = fmaf(a->y, 2.0f, -py);
+	a->x = px; a->y = py;
+}
+
+/* the same with T := -j T:  (-j)(T b) = (Im(T b), -Re(T b)) */
+static inline void o_bf_mj(cf *a, cf *b, cf t)
+{
+	float ux = fmaf( b->x, t.y, a->x);
+	float uy = fmaf( b->y, t.y, a->y);
+	float px = fmaf( b->y, t.x, ux);
+	float py = fmaf(-b->x, t.x, uy);
+	b->x = fmaf(a->x, 2.0f, -px);
+	b->y = fmaf(a->y, 2.0f, -py);
+	a->x = px; a->y = py;
+}
+
+/* T = 1 and T = -j: plain sums (fft.cl:86-94 with and without mul_p1q2) */
+static inline void o_bf1_mj(cf *a, cf *b)
+{
+	cf t;
+	t.x = a->x - b->y;  t.y = a->y + b->x;
+	a->x = a->x + b->y; a->y = a->y - b->x;
+	*b = t;
+}
+
+/* stage A of the first pass: the window taps ride on the butterfly */
+static inline void o_bf_win(cf *a, cf *b, float wa, float wb)
+{
+	float mx = a->x * wa, my = a->y * wa;
+	a->x = fmaf( b->x, wb, mx);
+	a->y = fmaf( b->y, wb, my);
+	b->x = fmaf(-b->x, wb, mx);
+	b->y = fmaf(-b->y, wb, my);
+}
+
+/* One Stockham radix-8 pass of the long plan (indexing of fft.cl:278-350).  win != NULL: the first pass (p = 1). */
+static void o_pass_radix8_fma(const cf *src, cf *dst, int n, int p, const float *win)
+{
+	const int t = n >> 3;
+	static const int perm[8] = { 0, 4, 2, 6, 1, 5, 3, 7 };
+	const cf w8 = o_tw(1, 4);
+	int i, j;
+
+	for (i = 0; i < t; i++) {
+		cf r[8];
+		const int k = i & (p - 1);
+		const int j0 = ((i - k) << 3) + k;
+
+		for (j = 0; j < 8; j++)
+			r[j] = src[i + j * t];
+
+		if (win) {
+			for (j = 0; j < 4; j++)
+				o_bf_win(&r[j], &r[j + 4], win[i + j * t], win[i + (j + 4) * t]);
+			o_dft2(&r[0], &r[2]); o_dft2(&r[1], &r[3]); o_bf1_mj(&r[4], &r[6]); o_bf1_mj(&r[5], &r[7]);
+			o_dft2(&r[0], &r[1]); o_bf1_mj(&r[2], &r[3]); o_bf(&r[4], &r[5], w8); o_bf_mj(&r[6], &r[7], w8);
+		} else {
+			const cf t4 = o_tw(4 * k, 4 * p), t2 = o_tw(2 * k, 4 * p), t1 = o_tw(k, 4 * p), t1w = o_tw(k + p, 4 * p);
+			for (j = 0; j < 4; j++)
+				o_bf(&r[j], &r[j + 4], t4);
+			o_bf(&r[0], &r[2], t2); o_bf(&r[1], &r[3], t2); o_bf_mj(&r[4], &r[6], t2); o_bf_mj(&r[5], &r[7], t2);
+			o_bf(&r[0], &r[1], t1); o_bf_mj(&r[2], &r[3], t1); o_bf(&r[4], &r[5], t1w); o_bf_mj(&r[6], &r[7], t1w);
+		}
+
+		for (j = 0; j < 8; j++)
+			dst[j0 + j * p] = r[perm[j]];
+	}
+}
+
+/* One Stockham radix-16 pass of the long plan: t = N/16 items of 16 points, angle -pi k / (8 p). */
+static void o_pass_radix16_fma(const cf *src, cf *dst, int n, int p, const float *win)
 {
 	const int t = n >> 4;
-	/* X[jj] sits in r[8 (jj & 1) + perm8[jj >> 1]] = r[bitrev4(jj)] */
+	/* X[m] sits in r[bitrev4(m)] */
 	static const int perm[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
+	const cf w16 = o_tw(1, 8), w8 = o_tw(2, 8), w163 = o_tw(3, 8);
 	int i, j;
 
 	for (i = 0; i < t; i++) {
 		cf r[16];
-		int k = i & (p - 1);
-		int j0;
+		const int k = i & (p - 1);
+		const int j0 = ((i - k) << 4) + k;
 
 		for (j = 0; j < 16; j++)
 			r[j] = src[i + j * t];
 
-		if (tw) {
-			float alpha = -ORACLE_PI_F * (float)k / (float)(8 * p);
-			for (j = 1; j < 16; j++)
-				r[j] = o_twiddle(r[j], j, alpha);
+		if (win) {
+			for (j = 0; j < 8; j++)
+				o_bf_win(&r[j], &r[j + 8], win[i + j * t], win[i + (j + 8) * t]);
+			for (j = 0; j < 4; j++) {
+				o_dft2(&r[j], &r[j + 4]);
+				o_bf1_mj(&r[8 + j], &r[12 + j]);
+			}
+			for (j = 0; j < 2; j++) {
+				o_dft2(&r[j], &r[j + 2]);
+				o_bf1_mj(&r[4 + j], &r[6 + j]);
+				o_bf(&r[8 + j], &r[10 + j], w8);
+				o_bf_mj(&r[12 + j], &r[14 + j], w8);
+			}
+			o_dft2(&r[0], &r[1]);       o_bf1_mj(&r[2], &r[3]);       o_bf(&r[4], &r[5], w8);     o_bf_mj(&r[6], &r[7], w8);
+			o_bf(&r[8], &r[9], w16);    o_bf_mj(&r[10], &r[11], w16); o_bf(&r[12], &r[13], w163); o_bf_mj(&r[14], &r[15], w163);
+		} else {
+			const int d = 8 * p;
+			const cf t8 = o_tw(8 * k, d), t4 = o_tw(4 * k, d), t2 = o_tw(2 * k, d), t2w = o_tw(2 * k + 2 * p, d);
+			const cf t1 = o_tw(k, d), t1a = o_tw(k + p, d), t1b = o_tw(k + 2 * p, d), t1c = o_tw(k + 3 * p, d);
+			for (j = 0; j < 8; j++)
+				o_bf(&r[j], &r[j + 8], t8);
+			for (j = 0; j < 4; j++) {
+				o_bf(&r[j], &r[j + 4], t4);
+				o_bf_mj(&r[8 + j], &r[12 + j], t4);
+			}
+			for (j = 0; j < 2; j++) {
+				o_bf(&r[j], &r[j + 2], t2);
+				o_bf_mj(&r[4 + j], &r[6 + j], t2);
+				o_bf(&r[8 + j], &r[10 + j], t2w);
+				o_bf_mj(&r[12 + j], &r[14 + j], t2w);
+			}
+			o_bf(&r[0], &r[1], t1);    o_bf_mj(&r[2], &r[3], t1);     o_bf(&r[4], &r[5], t1b);    o_bf_mj(&r[6], &r[7], t1b);
+			o_bf(&r[8], &r[9], t1a);   o_bf_mj(&r[10], &r[11], t1a);  o_bf(&r[12], &r[13], t1c);  o_bf_mj(&r[14], &r[15], t1c);
 		}
 
-		o_dft16(r);
-
-		j0 = ((i - k) << 4) + k;
 		for (j = 0; j < 16; j++)
 			dst[j0 + j * p] = r[perm[j]];
+	}
+}
+
+/* The final radix-2 pass of the long plan at N = 8192 (fft.cl:428-458: p = N/2, k = i): one butterfly with T = exp(-j pi k / p) */
+static void o_pass_radix2_fma(const cf *src, cf *dst, int n)
+{
+	const int p = n >> 1;
+	int i;
+	for (i = 0; i < p; i++) {
+		cf r0 = src[i], r1 = src[i + p];
+		o_bf(&r0, &r1, o_tw(i, p));
+		dst[i] = r0;
+		dst[i + p] = r1;
 	}
 }
 
@@ -225,22 +348,34 @@ static void o_fft_one(int log2n, const cf *in, cf *out, const float *win, cf *sc
 	cf *a = scratch, *b = scratch + n, *tmp;
 	int i, p, done;
 
+	if (log2n == 13 || log2n == 16) {
+		/* this build's plans for the long lengths (see o_pass_radix8_fma): the window rides on the first pass */
+		const int lr = (log2n == 16) ? 4 : 3;
+		const cf *src = in;
+		p = 1;
+		for (done = 0; done + lr <= log2n; done += lr) {
+			if (lr == 4)
+				o_pass_radix16_fma(src, b, n, p, p == 1 ? win : NULL);
+			else
+				o_pass_radix8_fma(src, b, n, p, p == 1 ? win : NULL);
+			tmp = a; a = b; b = tmp;
+			src = a;
+			p <<= lr;
+		}
+		if (log2n - done == 1) {
+			o_pass_radix2_fma(a, b, n);
+			tmp = a; a = b; b = tmp;
+		}
+		memcpy(out, a, sizeof(cf) * (size_t)n);
+		return;
+	}
+
 	for (i = 0; i < n; i++) {			/* fft.cl:415-417 */
 		a[i].x = in[i].x * win[i];
 		a[i].y = in[i].y * win[i];
 	}
 
 	p = 1;
-	if (log2n == 16) {
-		/* this build's plan for N = 65536: four radix-16 passes, p = 1, 16, 256, 4096 (see o_dft16) */
-		for (done = 0; done < 16; done += 4) {
-			o_pass_radix16(a, b, n, p, p > 1);
-			tmp = a; a = b; b = tmp;
-			p <<= 4;
-		}
-		memcpy(out, a, sizeof(cf) * (size_t)n);
-		return;
-	}
 	for (done = 0; done + 3 <= log2n; done += 3) {
 		o_pass_radix8(a, b, n, p, p > 1);
 		tmp = a; a = b; b = tmp;
