@@ -9,10 +9,10 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 T="timeout 300"
 $T python3 bench.py --steps 20 --warmup 5 "$@" > "$out/bench.json" 2> "$out/bench.err"
-$T python3 bench.py "$@" --no-cpu-baseline > "$out/bench_default.json" 2> "$out/bench_default.err"
-$T rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > "$out/bench_profiled.json" 2> "$out/kt.log"
-$T rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmcF" -o p -- python3 bench.py --steps 4 --warmup 2 --precondition 0.05 --no-cpu-baseline --no-traffic-twin --no-extra-passes "$@" > /dev/null 2> "$out/pmcF.log"
-$T rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$out/pmcW" -o p -- python3 bench.py --steps 4 --warmup 2 --precondition 0.05 --no-cpu-baseline --no-traffic-twin --no-extra-passes "$@" > /dev/null 2> "$out/pmcW.log"
+$T python3 bench.py "$@" --no-cpu-baseline --no-other-configs > "$out/bench_default.json" 2> "$out/bench_default.err"
+$T rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs "$@" > "$out/bench_profiled.json" 2> "$out/kt.log"
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmcF" -o p -- python3 bench.py --steps 4 --warmup 2 --precondition 0.05 --no-cpu-baseline --no-traffic-twin --no-extra-passes --no-other-configs "$@" > /dev/null 2> "$out/pmcF.log"
+$T rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$out/pmcW" -o p -- python3 bench.py --steps 4 --warmup 2 --precondition 0.05 --no-cpu-baseline --no-traffic-twin --no-extra-passes --no-other-configs "$@" > /dev/null 2> "$out/pmcW.log"
 find "$out/kt" -name "*_kernel_stats.csv" | head -1 | xargs cat | cut -c1-200 > "$out/kernel_stats.csv"
 timeout 120 python3 tools/kernel_union.py $(find "$out/kt" -name "*_kernel_trace.csv" | head -1) 3 > "$out/kernel_union.md"
 timeout 120 python3 tools/pmc_summary.py $(find "$out/pmcF" "$out/pmcW" -name "*counter_collection.csv") | cut -c1-200 > "$out/pmc.md"
