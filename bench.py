@@ -513,9 +513,9 @@ def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
         # (the launch condition of launch_k1: k1w_fft_bin unless FOSPHOR_AMD_K1W=0 or the hop is odd)
         k1w = os.environ.get("FOSPHOR_AMD_K1W", "1")[:1] != "0" and not (hop & 1)
         k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)",
-                   13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, overlap reused from registers)" if k1w else
+                   13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, FMA butterflies, overlap reused from registers)" if k1w else
                        "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
-                   16: "k1h_fused (K1, radix-16 plan: two 256-point levels in one kernel, intermediate in the XCD's L2)"}[cfg["log2n"]]
+                   16: "k1h_fused (K1, radix-16 plan of FMA butterflies: two 256-point levels in one kernel, intermediate in the XCD's L2)"}[cfg["log2n"]]
         if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
             k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"
         sub_b = samples_per_launch / samples_per_batch
@@ -620,7 +620,7 @@ def main():
         # no launcher started us: become the launcher's parent (child process; nothing in THIS process has touched the GPU)
         sys.exit(self_launch(args))
     # The library's two FFT streams must not share a hardware queue with each other or with RCCL's streams
-    # (HIP maps streams onto 4 queues by default; DESIGN.md section 5 "Hardware queues"): neutral at N=1 (measured).
+    # (HIP maps streams onto 4 queues by default; DESIGN_HISTORY.md section 5 "Hardware queues"): neutral at N=1 (measured).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist

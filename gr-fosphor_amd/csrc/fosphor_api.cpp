@@ -45,7 +45,7 @@ static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams *
  * evenly among them, and the count / merge kernels of the launch before run on the 32 it leaves free -- the dispatcher fills CUs it
  * finds empty, no CU mask involved (hardware masks that remove CUs unevenly from the shader engines unbalance a grid of CU-sized
  * work-groups: tools/ubench/cu_mask_big.hip).  Measured at BASELINE C3: 333 -> 367-371 GSamples/s with 28 batches per call, 358
- * with 14, 345 with 7; 232 / 240 CUs leave the tail too little (it becomes the longer side), 216: 356. */
+ * with 14, 345 with 7; 232 / 240 CUs leave the tail too little (it becomes the longer side), 216: 356 (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8). */
 static const int kK1wShareCus = 224;
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
@@ -498,7 +498,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	/* Measurement only, probe builds (-DFOSPHOR_AMD_PROBES; profiles/r04_ceiling.md): FOSPHOR_AMD_DBG_CUMASK=k reserves k CUs (k / 8 per XCD; mask bit i is CU i / 8 of
 	 * XCD i % 8, tools/ubench/cu_mask_probe.hip) for the count / merge streams and confines every FFT stream -- including the
 	 * instance's main stream, which is then the library's own and not the caller's -- to the rest.  Space-sharing by mask
-	 * measured far worse than the hardware's own interleaving; nothing in the product path sets it. */
+	 * measured far worse than the hardware's own interleaving (DESIGN_HISTORY.md 4a); nothing in the product path sets it. */
 #ifdef FOSPHOR_AMD_PROBES
 	{
 		const char *e = getenv("FOSPHOR_AMD_DBG_CUMASK");
@@ -558,7 +558,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	self->d_partial = self->d_partial_pp[0];
 	if (self->log2n == 16) {
 		/* One FFT kernel takes a spectrum through both 256-point levels of the radix-16 plan, the intermediate staying in the
-		 * XCD's L2 (the two-kernel form of rounds 1-3 went with the radix-8 plan in round 4). */
+		 * XCD's L2 (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8; the two-kernel form of rounds 1-3 went with the radix-8 plan in round 4). */
 		self->k1h_fused = 1;
 		/* 512 KiB of intermediate per cluster, at most 8 clusters on each of the 8 XCDs */
 		HIP_TRY(hipMalloc((void **)&self->d_scratch, sizeof(float2) * (size_t)64 * self->n), "alloc cluster intermediates");
@@ -861,7 +861,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 {
 	const double A = (double)self->histo_scale * 0.150514997831990597606869447362;
 	const double C = (double)self->histo_scale * (double)self->histo_offset;
-	/* |v_fast - v_pinned| bound, DESIGN.md "exact binning".  Part that does not scale with
+	/* |v_fast - v_pinned| bound, DESIGN.md section 2.3.  Part that does not scale with
 	 * |l2|: the float roundings of v itself and of the pinned chain (v < 256: <= 3e-5) plus
 	 * histo_scale x (pwr, pwr+offset roundings + the mult by log10(2)/2: <= 8e-7), doubled.
 	 * Part proportional to |l2| = |log2 s|: v_log_f32 (<= 1 ulp of l2) and the rounding of

@@ -375,7 +375,7 @@ struct BinConst { float A, C, amb, kappa; int nb; const double *thr; };
  * -- distance of the scaled log-power from the bin centre, plus the v_log_f32 error bound
  * (<= 1 ulp of l2, through the slope A: kappa = 2 * A * 2^-23, the factor 2 is margin; it also
  * covers the rounding of s32).  The guess is provably exact iff amb <= 0.5 - delta0, delta0
- * bounding the roundings that do not scale with l2 (DESIGN.md "exact binning").  amb is >= 0,
+ * bounding the roundings that do not scale with l2.  amb is >= 0,
  * +inf for |X|^2 in {0, denormal-flushed, inf}, NaN for NaN: compared as an unsigned bit
  * pattern all of those order above every finite value, so one running v_max_u32 per spectrum
  * collects "some sample needs the exact path" without per-sample compares or branches. */
@@ -508,7 +508,7 @@ void k1_fft_bin(const K1Params p)
 	 * element e lives at phys(e) = e ^ ((e >> 3) & 15): every access below is
 	 * bank-conflict free for ds_read_b64 (32-lane groups, 64 banks) and
 	 * ds_write_b64 (16-lane groups, 32 banks).  The closed forms per access
-	 * pattern are derived in DESIGN.md ("LDS exchange").                    */
+	 * pattern are derived in DESIGN_HISTORY.md ("LDS exchange").                    */
 	const int rd_even = lane ^ ((lane >> 3) & 7);		/* e = lane + 64m, m even */
 	const int rd_odd  = rd_even ^ 8;			/*                 m odd  */
 	const int st1     = (8 * lane) ^ (lane & 15);		/* pass 1: e = 8i + jj, i = lane (+64v)   */
@@ -1051,7 +1051,7 @@ void k1v2_fft_bin(const K1Params p)
  * the N-point exchange slab in dynamic LDS (64 KiB at 8192), twiddles and window read from
  * global memory (L2-resident tables; this path is a parity case, not the tuned one).
  * Same swizzle phys(e) = e ^ ((e >> 3) & 15): the store patterns of every pass and the
- * lane-contiguous reads stay bank-conflict free for any N (the argument of DESIGN.md only
+ * lane-contiguous reads stay bank-conflict free for any N (the argument of DESIGN_HISTORY.md only
  * involves address bits 0..6).  Bin indices are 16-bit, 2 spectra per dword. */
 static __device__ __forceinline__ int swz(int e) { return e ^ ((e >> 3) & 15); }
 
@@ -1564,7 +1564,7 @@ void k1w_fft_bin(const K1Params p)
  * Bin indices: 512 bins need 9 bits.  The low 8 bits go out like the 1024-point path's (one dword = 4 consecutive spectra of
  * a column), the 9th as one bit per spectrum in a dword per (tile, column): 1.125 B per sample instead of 2.
  *
- * THE LOOP IS SKEWED ("C5, round 4", has the measurement behind every choice).  A spectrum's blocks make a round
+ * THE LOOP IS SKEWED (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8, "C5, round 4", has the measurement behind every choice).  A spectrum's blocks make a round
  * trip store -> L2 -> cluster barrier -> load; with the loop in program order all eight waves of a CU sat through it (132 of 326 us).
  * Instead the same threads run stage A of spectrum u + 1 meanwhile: its first pass between the stores of spectrum u and their
  * s_waitcnt vmcnt(0), its wave-internal transpose and pass-2 twiddle products between the arrival at the cluster barrier and

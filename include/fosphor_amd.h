@@ -70,7 +70,7 @@ int fosphor_amd_process_device(struct fosphor *self, const void *d_samples,
  * overlap_cc(N, overlap) would have produced.
  * (fft_len_log = 13: a call whose spectra count is a multiple of 14 336 = 224 tiles of 64 -- e.g. 14 or 28 batches of 4096 --
  * issued while the previous call is still being counted lets the FFT kernel run on 224 CUs and the count / merge kernels of the
- * previous launch on the other 32: +10 % throughput, identical results) */
+ * previous launch on the other 32: +10 % throughput, identical results; DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8.) */
 int fosphor_amd_process_device_overlap(struct fosphor *self, const void *d_samples,
                                        int n_batches, int batch, int overlap);
 
@@ -91,7 +91,7 @@ int fosphor_amd_finish(struct fosphor *self);
  * d_waterfall is one of two rings and must be re-queried after every process call (a call that rewrites
  * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering).
  * At fft_len_log = 16 the waterfall rings are UNCACHED device memory (hipDeviceMallocUncached: the kernel's row stores must not
- * pass through the L2 that holds its intermediate): any kernel or copy may read them, reads simply are not
+ * pass through the L2 that holds its intermediate, DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8): any kernel or copy may read them, reads simply are not
  * cached (FOSPHOR_AMD_UC_OUTPUTS=0 in the environment gives plain memory). */
 struct fosphor_amd_buffers
 {

@@ -121,7 +121,7 @@ def pipe(n_calls):
 
 
 def share(n_pairs):
-    """N = 8192 in the space-sharing form: calls of 14 batches of 1024 spectra (448 tiles: the FFT launch
+    """N = 8192 in the space-sharing form (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8): calls of 14 batches of 1024 spectra (448 tiles: the FFT launch
     runs on 224 CUs when the previous call's count / merge kernels are still pending), issued in PAIRS without looking at the
     results in between; after each pair the last batch's counts bit-exact and the state in tolerance against the oracle,
     which has seen the same 28 batches one by one."""

@@ -58,7 +58,7 @@ def test_piece_planner_host_logic(amd):
     """fosphor_amd_plan_piece_batches: how a device-resident call is cut into sub-launches (pure host arithmetic).  Pieces are
     about sub_samples samples and equal; at fft_len_log = 13 with the streams on they are whole multiples of the unit that makes
     a piece's tiles (64 spectra each) a multiple of 224, so that the FFT launch can leave CUs to the count / merge kernels
-     -- when the call's batch count allows it."""
+    (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8) -- when the call's batch count allows it."""
     plan = amd.load().fosphor_amd_plan_piece_batches
     assert plan(10, 1, 256, 1024, 1 << 26) == 64		# the C2 bench call: 4 pieces of 64 reference batches
     assert plan(10, 1, 100, 1024, 1 << 26) == 50		# equal pieces, not 64 + 36

@@ -488,7 +488,7 @@ def test_c3_full_batch_properties(amd, torch_cuda, oracle_built):
 
 @pytest.mark.parametrize("over,F,sub_log2", [(2, 14, None), (4, 28, "27")])
 def test_c3_space_sharing_is_bit_identical(amd, torch_cuda, monkeypatch, over, F, sub_log2):
-    """N = 8192, space sharing: a call whose tiles are a multiple of 224 -- here 14 batches of 1024
+    """N = 8192, space sharing (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8): a call whose tiles are a multiple of 224 -- here 14 batches of 1024
     spectra = 448 tiles of 32 -- runs its FFT kernel on 224 work-groups and the count / merge kernels of the PREVIOUS launch on
     the CUs it leaves free.  Two such calls back to back (the second call's FFT kernel beside the first call's count and merge)
     must leave exactly the state of the single-stream form (fosphor_amd_set_overlap(0): 256 work-groups, one kernel at a
@@ -1331,7 +1331,7 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overl
 
 def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
     """N = 65536 in two 256-point levels (passes p = 1, 16 per residue mod 256 inside a wavefront; passes p = 256, 4096 per
-    offset mod 256 in a work-group; the spectrum between them in the XCD's L2): the bits of the oracle's radix-16 plan
+    offset mod 256 in a work-group; the spectrum between them in the XCD's L2): the bits of the oracle's radix-16 plan of FMA butterflies
     (this build's own plan at this length: no reference behaviour exists), fp32 and fp16 input."""
     torch = torch_cuda
     n = 65536

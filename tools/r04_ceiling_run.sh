@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON the GPU box (gpurun -- 'bash tools/r04_ceiling_run.sh'): the ceiling probes of DESIGN.md 4a, raw bench lines kept.
+# Run ON the GPU box (gpurun -- 'bash tools/r04_ceiling_run.sh'): the ceiling probes of DESIGN_HISTORY.md 4a, raw bench lines kept.
 # Every line is `bench.py --steps 40 --warmup 8 --no-cpu-baseline` on C2 (256 bins, batch mode), two repetitions each.
 OUT=gpurun_out/r04_ceiling
 mkdir -p $OUT
