@@ -1858,7 +1858,23 @@ void k1h_fused(const K1Params p)
 		wave_lds_sync();
 	};
 	/* pass 2, p = 16, k = ia */
+#ifndef K1H_TW_REGS
+#define K1H_TW_REGS 0		/* 1: the pass-2 / pass-3 twiddles of a thread (fixed for its lifetime) in registers instead of 16 LDS reads per spectrum.
+				 * Measured (round 5): the kernel ALONE 2.6 % faster (15 850 against 16 270 cycles per spectrum, K1H_TIMING builds) -- and the
+				 * path 10 % slower (209 against 231 GSamples/s, three interleaved runs each): 233 instead of 209 VGPRs leave the scan / merge
+				 * kernels of the previous frame no registers on a CU this kernel occupies, and the frame's tail no longer runs beside it */
+#endif
+#if K1H_TW_REGS
+	v2f twa_r[8], tw3_r[8];
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		twa_r[j] = twa_t[ia * kTwRow + j];
+		tw3_r[j] = tw3_t[kkl * kTwRow + j];
+	}
+#else
 	const v2f *twa_r = twa_t + ia * kTwRow;
+	const v2f *tw3_r = tw3_t + kkl * kTwRow;
+#endif
 	auto stage_a2_ab = [&]() { pass16_ab(ra, twa_r[0], twa_r[1], two); };
 	auto stage_a2_cd = [&]() { pass16_cd(ra, twa_r[2], twa_r[3], twa_r[4], twa_r[5], twa_r[6], twa_r[7], two); };
 	auto stage_a2 = [&]() { stage_a2_ab(); stage_a2_cd(); };
@@ -1986,8 +2002,7 @@ void k1h_fused(const K1Params p)
 			}
 		}
 		K1H_STAMP(7);		/* loads of the intermediate issued + second pass of the next spectrum */
-		const v2f *tw3_r = tw3_t + kkl * kTwRow;			/* pass 3, p = 256, k = kk */
-		pass16_ab(r, tw3_r[0], tw3_r[1], two);
+		pass16_ab(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
 #if K1H_TIMING
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
