@@ -616,8 +616,9 @@ def _bench_iq(torch, n_samples, seed, tone):
 
 
 def test_bench_launch_shape_vs_oracle(amd, torch_cuda, oracle_built):
-    """The launch shape bench.py times (BASELINE C2, the headline): 256 bins, ONE fosphor_amd_process_device call of
-    256 x 1024 spectra = 2^28 samples -- four 64-batch sub-launches on alternating FFT streams, relaxed input ordering --
+    """Hit counts bit-exact for the LAST of 512 batches only (the only counts a call exposes); the other 511 are seen through the
+    float state they went into, in tolerance.  The launch shape bench.py times (BASELINE C2, the headline): 256 bins, ONE
+    fosphor_amd_process_device call of 256 x 1024 spectra = 2^28 samples -- four 64-batch sub-launches on alternating FFT streams, relaxed input ordering --
     then a second such call on the other half of the input ring, queued behind the first without a host wait in between.
     Semantics: cl.c:870-968 applied 256 times per call.  The oracle takes the same 512 batches one fosphor_process at a
     time: the last batch's hit counts equal it bit for bit and the state every one of the 512 batches went into --
