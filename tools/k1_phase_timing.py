@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of K1 from a K1_TIMING=1 build (debug only).
 
-    hipcc ... -DK1_TIMING=1 -o build/ab/lib_timing.so ...      (tools/ab_bench.sh builds it)
+    hipcc ... -DK1_TIMING=1 -o build/ab/lib_timing.so ...      (tools/ab_build.sh "timing:-DK1_TIMING=1" builds it)
     FOSPHOR_AMD_LIB=build/ab/lib_timing.so FOSPHOR_AMD_K1_TIMING=1 FOSPHOR_AMD_OVERLAP=0 python3 tools/k1_phase_timing.py
 """
 import ctypes as C
