@@ -1247,6 +1247,7 @@ def test_sink_native_feed_keeps_uploads_in_flight(amd, torch_cuda, oracle_built)
     samples = C.c_uint64()
     L.fosphor_amd_sink_stats(s, None, C.byref(samples), None, None, None)
     assert samples.value == n_spec * 1024
+    assert L.fosphor_amd_sink_dropped(s) == 0			# nothing was refused by the device
     core = L.fosphor_amd_sink_core(s)
     wf = np.empty((1024, 1024), np.float32)
     assert L.fosphor_amd_read(core, 0, wf.ctypes.data, wf.nbytes) == 0
@@ -1736,5 +1737,11 @@ def test_capacity_and_argument_errors(amd, torch_cuda):
     with pytest.raises(RuntimeError):
         amd.Fosphor(wf_rows=1000)				# not a power of two
     with pytest.raises(RuntimeError):
-        amd.Fosphor(fft_len_log=11)				# only 2^10 and 2^13 in this round
+        amd.Fosphor(fft_len_log=11)				# only 2^10, 2^13 and 2^16
+    # fosphor_amd_share_stats: zeros for an instance that never shares (N = 1024); the split this device would use; NULL pointers allowed
+    import ctypes as C
+    L = amd.load()
+    assert f.share_stats() == (0, 0, 224)
+    assert L.fosphor_amd_share_stats(f.h, None, None, None) == 0
+    assert L.fosphor_amd_share_stats(None, None, None, None) == -errno.EINVAL
     f.close()
