@@ -193,22 +193,26 @@ def test_bench_frame_mode_two_ranks_one_gpu(tmp_path):
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
 
 
-def test_bench_self_launch_two_ranks_one_gpu():
-    """`python3 bench.py --gpus 2` with NO launcher in the environment: bench.py itself starts torch.distributed.run as a child
-    process (before any GPU call in the parent), relays rank 0's one JSON line and the child's exit code.  Two ranks share this
-    GPU (test hooks: FOSPHOR_BENCH_ONE_GPU puts every rank on device 0, the ranks talk over gloo as in the test above)."""
+@pytest.mark.parametrize("world,extra", [(2, []), (8, ["--batches-per-step", "16"])])
+def test_bench_self_launch_ranks_on_one_gpu(world, extra):
+    """`python3 bench.py --gpus N` with NO launcher in the environment: bench.py itself starts torch.distributed.run as a child
+    process (before any GPU call in the parent), relays rank 0's one JSON line and the child's exit code.  The N ranks share this
+    GPU (test hooks: FOSPHOR_BENCH_ONE_GPU puts every rank on device 0, the ranks talk over gloo as in the test above).  N = 8 is
+    the driver's largest run: launcher, process group, transport agreement, the 8-way time split of a frame, the max-over-ranks
+    timing and the one JSON line are exercised at that world size before the first real 8-GPU contact."""
     import json
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(FOSPHOR_BENCH_BACKEND="gloo", FOSPHOR_AMD_EXCHANGE="torch", FOSPHOR_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--ring-steps", "1",
-           "--precondition", "0.05", "--no-cpu-baseline", "--no-extra-passes", "--no-traffic-twin"]
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--ring-steps", "1",
+           "--precondition", "0.05", "--no-cpu-baseline", "--no-extra-passes", "--no-traffic-twin"] + extra
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, "%s\n%s" % (p.stdout[-2000:], p.stderr[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["config"]["mode"] == "frame" and j["value"] > 0
+    assert j["n_gpus"] == world and j["steps"] == 3 and j["config"]["mode"] == "frame" and j["value"] > 0
+    assert len(j["config"]["k1_busy_ms_per_launch_per_rank"]["all"]) == world
     assert "torch.distributed.run" in p.stderr
