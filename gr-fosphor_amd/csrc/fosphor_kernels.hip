@@ -1532,6 +1532,35 @@ void k1w_fft_bin(const K1Params p)
 #undef K1W_EPI
 }
 
+/* Buffer addressing for the 65536-point kernel: every global access of its loop is `scalar base (descriptor) + ONE 32-bit per-lane
+ * offset + a scalar offset` -- buffer_load / buffer_store ... offen -- where the per-lane offset is fixed for the kernel's lifetime and
+ * everything that changes (spectrum, row, column block c) is scalar arithmetic.  With plain pointers the compiler folded the
+ * column-block constants into 64-bit per-lane adds (240 of them per spectrum) and spilled.  Arrays addressed this way are < 4 GiB. */
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
+{
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);	/* raw buffer, 32-bit data format */
+}
+constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of the buffer intrinsics: nt, sc1 */
+#ifndef K1H_OUT_AUX
+#define K1H_OUT_AUX 2				/* cache policy of the 65536-point kernel's row / index stores (A/B builds) */
+#endif
+#ifndef K1H_IQ_MOD
+#define K1H_IQ_MOD "nt"				/* ... and of its LDS-DMA of the IQ */
+#endif
+template <int AUX>
+static __device__ __forceinline__ void bst_v2f(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+	__builtin_amdgcn_raw_buffer_store_b64(u2v{ __float_as_uint(v.x), __float_as_uint(v.y) }, rs, voff, soff, AUX);
+}
+template <int AUX>
+static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+	const u2v u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
+	return v2f{ __uint_as_float(u.x), __uint_as_float(u.y) };
+}
+
 /* ------------------------------------------------------------------------ */
 /* K1 for N = 65536: radix-16 plan, two stages, the intermediate in the XCD's L2 */
 /* ------------------------------------------------------------------------ */
@@ -1602,35 +1631,6 @@ void k1w_fft_bin(const K1Params p)
 #endif
 /* X[jj] of a radix-16 pass sits in r[bitrev4(jj)] */
 #define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))
-
-/* Buffer addressing for the 65536-point kernel: every global access of its loop is `scalar base (descriptor) + ONE 32-bit per-lane
- * offset + a scalar offset` -- buffer_load / buffer_store ... offen -- where the per-lane offset is fixed for the kernel's lifetime and
- * everything that changes (spectrum, row, column block c) is scalar arithmetic.  With plain pointers the compiler folded the
- * column-block constants into 64-bit per-lane adds (240 of them per spectrum) and spilled.  Arrays addressed this way are < 4 GiB. */
-typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
-{
-	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0xffffffff, 0x00020000);	/* raw buffer, 32-bit data format */
-}
-constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of the buffer intrinsics: nt, sc1 */
-#ifndef K1H_OUT_AUX
-#define K1H_OUT_AUX 2				/* cache policy of the 65536-point kernel's row / index stores (A/B builds) */
-#endif
-#ifndef K1H_IQ_MOD
-#define K1H_IQ_MOD "nt"				/* ... and of its LDS-DMA of the IQ */
-#endif
-template <int AUX>
-static __device__ __forceinline__ void bst_v2f(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
-{
-	__builtin_amdgcn_raw_buffer_store_b64(u2v{ __float_as_uint(v.x), __float_as_uint(v.y) }, rs, voff, soff, AUX);
-}
-template <int AUX>
-static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
-{
-	const u2v u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
-	return v2f{ __uint_as_float(u.x), __uint_as_float(u.y) };
-}
 
 constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [residue 4][jj 16][a 16], rows padded to 17 */
 constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
