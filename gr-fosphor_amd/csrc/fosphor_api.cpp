@@ -122,7 +122,6 @@ struct fosphor
 	int       kn_rowmask_off;		/* FOSPHOR_AMD_ROWMASK=0: dense count hand-off at N = 65536 */
 	int       kn_no_sum16;			/* FOSPHOR_AMD_NO_SUM16 */
 	int       kn_frame_group;		/* FOSPHOR_AMD_FRAME_GROUP: chunks per count work-group of a sharded frame (default 4) */
-	int       kn_k1w_off;			/* FOSPHOR_AMD_K1W=0: the general kernel at N = 8192 */
 	int       kn_k1w_share_off;		/* FOSPHOR_AMD_K1W_SHARE=0: no space sharing at N = 8192 */
 	int       n_cus;			/* hipDeviceProp_t::multiProcessorCount */
 	int       share_cus;			/* N = 8192: work-groups of an FFT launch that leaves CUs to the count / merge kernels (0: never) */
@@ -201,12 +200,10 @@ struct fosphor
  * o_pass_radix8_fma / o_pass_radix16_fma / o_pass_radix2_fma, restates them): the reference's Stockham passes with the twiddles
  * ON the radix-2 butterflies of a pass instead of on its inputs, so an item needs the twiddles of its stages -- every one of them
  * exp(-j pi q / den) for integers q, den, formed like the reference's (one float expression, pinned sin / cos): tw_long().
- *   N = 8192:   blocks 0-2  passes p = 8, 64, 512: [k < p][4] = w^4, w^2, w, w W8          (w = exp(-j pi k / (4 p)))
+ *   both:       block  0    the constants W16, W8, W16^3 (first pass)
+ *   N = 8192:   blocks 1-2  passes p = 16, 256: [k < p][8] = w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3   (w = exp(-j pi k / (8 p)))
  *               block  3    the radix-2 pass: [k < 4096] = exp(-j pi k / 4096)
- *               block  4    the constant W8 (first pass)
- *   N = 65536:  block  0    the constants W16, W8, W16^3 (first pass)
- *               blocks 1-3  passes p = 16, 256, 4096: [k < p][8] = w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3
- *                                                                                           (w = exp(-j pi k / (8 p))) */
+ *   N = 65536:  blocks 1-3  passes p = 16, 256, 4096: [k < p][8], as above */
 static float2 tw_long(int q, int den)
 {
 	const float PI_F = 3.141592653589f;		/* fft.cl:26 */
@@ -241,26 +238,28 @@ static int build_twiddles13(float2 *tw, int *offsets /* [8] or NULL */)
 {
 	const int n = 8192;
 	int pos = 0, q = 0;
-	for (int p = 8; p < n / 2; p *= 8, q++) {
+	if (offsets) offsets[q] = pos;
+	q++;
+	for (int m = 1; m <= 3; m++) {
+		if (tw) tw[pos] = tw_long(m, 8);
+		pos++;
+	}
+	for (int p = 16; p <= 256; p *= 16, q++) {
 		if (offsets) offsets[q] = pos;
-		const int d = 4 * p;
+		const int d = 8 * p;
 		for (int k = 0; k < p; k++) {
-			const int qs[4] = { 4 * k, 2 * k, k, k + p };
-			for (int f = 0; f < 4; f++) {
+			const int qs[8] = { 8 * k, 4 * k, 2 * k, 2 * k + 2 * p, k, k + p, k + 2 * p, k + 3 * p };
+			for (int f = 0; f < 8; f++) {
 				if (tw) tw[pos] = tw_long(qs[f], d);
 				pos++;
 			}
 		}
 	}
 	if (offsets) offsets[q] = pos;
-	q++;
 	for (int k = 0; k < n / 2; k++) {
 		if (tw) tw[pos] = tw_long(k, n / 2);
 		pos++;
 	}
-	if (offsets) offsets[q] = pos;
-	if (tw) tw[pos] = tw_long(1, 4);
-	pos++;
 	return pos;
 }
 
@@ -491,7 +490,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		e = getenv("FOSPHOR_AMD_ROWMASK");     self->kn_rowmask_off = (e && *e == '0');
 		self->kn_no_sum16 = getenv("FOSPHOR_AMD_NO_SUM16") != NULL;
 		e = getenv("FOSPHOR_AMD_FRAME_GROUP"); self->kn_frame_group = e ? atoi(e) : 4;
-		e = getenv("FOSPHOR_AMD_K1W");         self->kn_k1w_off = (e && *e == '0');
 		e = getenv("FOSPHOR_AMD_K1W_SHARE");   self->kn_k1w_share_off = (e && *e == '0');
 	}
 
@@ -906,7 +904,6 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 #endif
 	k1->iq_half = self->iq_half;
 	k1->n_cus = self->n_cus;
-	k1->k1w_off = self->kn_k1w_off;
 	{
 		const int sc = self->share_cus;
 		k1->cus = (self->log2n == 13 && self->overlap && !self->kn_k1w_share_off && sc > 0 && tile > 0 && (total / tile) % sc == 0) ? sc : 0;

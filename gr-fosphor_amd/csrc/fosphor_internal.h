@@ -60,7 +60,6 @@ struct K1Params {
 	int   cus;			/* N = 8192: work-groups (= CUs) of the FFT launch when it leaves CUs to the count / merge kernels
 					 * (kK1wShareCus; the launch's tiles are a multiple of it), 0 = every CU */
 	int   n_cus;			/* CUs of the device (0: 256) */
-	int   k1w_off;			/* N = 8192: use the general kernel (FOSPHOR_AMD_K1W=0, read at init) */
 	int   variant;			/* 1: one wave per spectrum; 2: two waves per spectrum (odd hops); 3: general N (N/8 threads per
 					 * spectrum, one LDS slab); 4: N = 65536 in two LDS stages */
 };

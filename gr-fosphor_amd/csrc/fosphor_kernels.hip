@@ -1228,311 +1228,7 @@ void k1big_fft_bin(const K1Params p)
 	}
 }
 
-/* ------------------------------------------------------------------------ */
-/* K1 for N = 8192: 512 threads per spectrum, 16 points per thread            */
-/* ------------------------------------------------------------------------ */
-/* The same plan as k1big_fft_bin<13> (radix-8 passes p = 1, 8, 64, 512 and the radix-2 pass p = 4096 over 1024 virtual
- * work-items of 8 points, fft.cl:278-350,397-466 generalised) with the structure of the 1024-point kernel:
- *   - a thread runs TWO virtual work-items per pass: (2 th, 2 th + 1) in pass 1 -- what 16-byte IQ loads deliver --
- *     and (th, th + 512) in passes 2-4, whose twiddle index k = i & (p - 1) is the same for both.  With both items
- *     of a pair in one thread the exchange between the p = 512 pass and the radix-2 pass is the identity (item
- *     th + 512 v stores e = 4096 v + th + 512 jj, the radix-2 butterflies of the thread are (th + 512 jj, + 4096)):
- *     three exchanges through LDS instead of five, each with ONE barrier (two 64 KiB slabs used alternately: the
- *     barrier behind the stores of an exchange also proves that every thread has finished the loads of the exchange
- *     before the previous one, i.e. of the slab written next);
- *   - everything a thread needs from the tables is fixed per thread: 16 window taps and 3 x 7 twiddles of the
- *     radix-8 passes sit in 58 registers; the radix-2 pass's 4096 twiddles in the 32 KiB of LDS the slabs leave;
- *   - the overlap of overlap_cc (overlap_cc_impl.cc:64-79) lives in REGISTERS: a thread holds the raw IQ of elements
- *     (2 th, 2 th + 1) + 1024 j, j < 8; the next window of a tile starts hop = N / R samples later, i.e. 8 / R strides
- *     of 1024 -- its element j is this window's element j + 8 / R of the same thread.  With R = 2 (BASELINE C3) a
- *     spectrum costs four 16-byte loads per thread: every sample of the stream is fetched once (the first spectrum of a
- *     tile loads all eight).  The loads for the next spectrum are issued before the FFT of the current one.
- * One work-group (8 waves, <= 256 registers) per CU.  Same arithmetic and outputs as k1big_fft_bin<13> (bit-identical
- * FFT, bins, rows; 16-bit bin indices, 2 spectra per dword). */
-/* Work-group barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its outstanding
- * global loads and stores (__syncthreads() also drains vmcnt, which would park every wave of the work-group behind the
- * IQ requested for the NEXT spectrum).  Nothing is handed from thread to thread through global memory in these kernels. */
-static __device__ __forceinline__ void wg_barrier_lds()
-{
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <bool WRITE_FFT>
-__global__ __launch_bounds__(512, 2)
-void k1w_fft_bin(const K1Params p)
-{
-	constexpr int N = 8192, TH = 512;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	/* two 64 KiB slabs; a spectrum's three exchanges use A, B, A and the next spectrum's B, A, B: whenever a slab is stored
-	 * to, a barrier lies between those stores and the last loads from it */
-	v2f *slab0 = reinterpret_cast<v2f *>(smem_raw);
-	v2f *slab1 = slab0 + N;
-	/* behind the slabs: the exact-bin thresholds (n_bins + 1 <= 513 doubles).  The rare path that consults them runs in every other
-	 * wave-spectrum at 512 bins, and while one wave is in it the other seven wait at the next barrier: a look-up through the scalar cache
-	 * cost 29 us of 330 per launch (probe with an empty body: 301), ds_read costs less.  (The radix-2 twiddles that used to sit here are
-	 * eight per thread, fixed for its lifetime: registers.) */
-	typedef const __attribute__((address_space(3))) double *lds_cdp;
-	double *thr_g = reinterpret_cast<double *>(slab0 + 2 * N);
-	const lds_cdp thr_l = (lds_cdp)thr_g;
-
-	const int th = threadIdx.x;
-	const int ntiles = p.total / p.tile;
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-	const v2f two = { 2.0f, 2.0f };
-	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
-	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
-	const float top = (float)(bk.nb - 1);
-
-	/* ---- per-thread constants (the long plan, see bf(): 4 twiddles per item and pass) -------- */
-	v2f wab[2][4];			/* wab[v][j]: taps of elements 2 th + v + 1024 j and + 1024 (j + 4): the pair of a first-pass stage-A butterfly */
-	v2f tw8[4], tw64[4], tw512[4];	/* w^4, w^2, w, w W8 for k = th & 7, th & 63, th (both items of a pair) */
-	v2f twr[8];			/* radix-2 twiddles k = th + 512 c */
-	const v2f w8c = twg[p.tw_off[4]];
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		const v2f lo = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * j);
-		const v2f hi = *reinterpret_cast<const v2f *>(p.win + 2 * th + 1024 * (j + 4));
-		wab[0][j] = v2f{ lo.x, hi.x };
-		wab[1][j] = v2f{ lo.y, hi.y };
-	}
-#pragma unroll
-	for (int j = 0; j < 8; j++)
-		twr[j] = twg[p.tw_off[3] + th + 512 * j];
-	for (int e = th; e <= p.n_bins && e < 520; e += TH)
-		thr_g[e] = p.thr[e];
-	__syncthreads();
-#pragma unroll
-	for (int n = 0; n < 4; n++) {
-		tw8[n]   = twg[p.tw_off[0] + (th & 7) * 4 + n];
-		tw64[n]  = twg[p.tw_off[1] + (th & 63) * 4 + n];
-		tw512[n] = twg[p.tw_off[2] + th * 4 + n];
-	}
-
-	/* ---- LDS addressing (8-byte elements, phys(e) = e ^ ((e >> 3) & 15) as in the other kernels) ----
-	 * loads of every pass: e = th + 512 m -> phys = rd + 512 m;  stores: pass 1 e = 16 th + 8 v + jj,
-	 * pass 2 e = 64 (th >> 3) + (th & 7) + 4096 v + 8 jj, pass 3 e = 512 (th >> 6) + (th & 63) + 4096 v + 64 jj */
-	const int rd  = th ^ ((th >> 3) & 15);
-	const int e1a = 16 * th, e1b = 16 * th + 8;
-	const int st1a = e1a ^ ((e1a >> 3) & 15), st1b = e1b ^ ((e1b >> 3) & 15);	/* ^ jj below: jj < 8 touches bits 0-2 only */
-	/* pass 2: swz(64 (th >> 3) + (th & 7) + 8 jj) in closed form: bits 0-2 (th & 7) ^ jj, bit 3 (jj & 1) ^ ((th >> 3) & 1), bits 4-5
-	 * jj >> 1 -- one XOR with a constant per store */
-	const int st2 = 64 * (th >> 3) + 8 * ((th >> 3) & 1) + (th & 7);
-	const int e3 = 512 * (th >> 6) + (th & 63);
-	const int st3 = e3 ^ ((e3 >> 3) & 15);						/* + 64 jj: (64 jj >> 3) & 15 = (8 jj) & 15 */
-
-	/* hop = N / R with R = 2, 4, 8: the next window's element j is this window's element j + shift of the same thread */
-	const int shift = (p.hop == N / 2) ? 4 : (p.hop == N / 4) ? 2 : (p.hop == N / 8) ? 1 : 0;
-
-	v4f q[8];			/* raw IQ of the spectrum to be processed next */
-	uint16_t *bins16 = reinterpret_cast<uint16_t *>(p.bins);
-
-	/* Epilogue of columns [M0, M1) of spectrum tp, whose FFT is in xo: log-power, exact 16-bit bin, live / max, waterfall row
-	 * (display.cl:136-150,161-168).  Per column, nothing carried from column to column: it is cut into three pieces that
-	 * run between the LDS stores of the NEXT spectrum's exchanges and the barrier behind them, i.e. while this wave
-	 * would otherwise wait for the slowest one. */
-#ifndef K1W_P1
-#define K1W_P1 6		/* the three epilogue pieces: columns [0, P1), [P1, P2), [P2, 16) of a thread (A/B builds) */
-#define K1W_P2 11
-#endif
-#define K1W_EPI(M0, M1, tp) do { \
-		const bool _row = ((tp) >= p.wf_first); \
-		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + th; \
-		/* index stores: scalar base (+ 4 KiB per two columns of a thread: SALU) + ONE lane offset + immediate -- the flat form cost a \
-		 * 64-bit VALU add (and its hazard nop) per store */ \
-		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2 + ((tp) & 1)); \
-		const uint32_t _bo = 4u * (uint32_t)th; \
-		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
-		_Pragma("unroll") \
-		for (int m = (M0); m < (M1); m++) { \
-			uint32_t ab; \
-			const float rr = bin_fast(xo[m].x, xo[m].y, bk, &_l2[m - (M0)], &ab); \
-			_amb = _amb > ab ? _amb : ab;		/* v_max_u32: NaN / inf order above every finite measure */ \
-			_bn[m - (M0)] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top); \
-		} \
-		/* ONE branch per piece (a compare + exec save + branch per sample cost 9 % of this kernel): rare -- find the samples again \
-		 * and decide them against the exact thresholds */ \
-		if (!K1_DBG_NO_EXACT && _amb > __float_as_uint(bk.amb)) { \
-			_Pragma("unroll") \
-			for (int m = (M0); m < (M1); m++) { \
-				const float v = __builtin_fmaf(bk.A, _l2[m - (M0)], bk.C); \
-				const float a = __builtin_fmaf(__builtin_fabsf(_l2[m - (M0)]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v))); \
-				if (!(a <= bk.amb)) { \
-					float nl2; \
-					_bn[m - (M0)] = bin_exact(xo[m].x, xo[m].y, _l2[m - (M0)], (int)_bn[m - (M0)], thr_l, bk.nb, &nl2); \
-					_l2[m - (M0)] = nl2; \
-				} \
-			} \
-		} \
-		_Pragma("unroll") \
-		for (int m = (M0); m < (M1); m++) { \
-			const float l2v = _l2[m - (M0)]; \
-			if ((m & 1) == 0) \
-				asm volatile("global_store_short %0, %1, %2" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_bdu + 4096 * (m >> 1)) : "memory"); \
-			else \
-				asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_bdu + 4096 * (m >> 1)) : "memory"); \
-			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
-			vmax[m] = max_f32(vmax[m], l2v); \
-		} \
-		if (_row) {		/* uniform, rare (the last wf_rows spectra of a call): one branch per piece instead of one per sample; the row \
-					 * values are recomputed from the log-powers, which the live / max updates above kept alive anyway */ \
-			_Pragma("unroll") \
-			for (int m = (M0); m < (M1); m++) \
-				_wf[TH * m] = _l2[m - (M0)] * F_HALF_LOG10_2; \
-		} \
-	} while (0)
-
-	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-	const int t0 = tile * p.tile;
-	float live[16], vmax[16];
-#pragma unroll
-	for (int m = 0; m < 16; m++) { live[m] = 0.0f; vmax[m] = vmax_init; }
-
-	{
-		const float2 *src = p.iq + (size_t)t0 * p.hop + 2 * th;
-#pragma unroll
-		for (int j = 0; j < 8; j++)
-			q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
-	}
-
-	v2f xo[16];			/* FFT of the previous spectrum of the tile, its epilogue still to do */
-#pragma unroll
-	for (int m = 0; m < 16; m++) xo[m] = v2f{ 0.0f, 0.0f };
-
-#pragma unroll 1
-	for (int g = 0; g < p.tile; g++) {
-		const int t = t0 + g;
-		const bool have_prev = g > 0;			/* uniform */
-		/* The two waves of a SIMD (waves w and w + 4 of the work-group) run their epilogue pieces on opposite sides of the barrier:
-		 * one computes while the other waits for its LDS loads, instead of all eight moving from LDS to VALU and back together */
-		const bool late = (__builtin_amdgcn_readfirstlane(th >> 6) & 4) != 0;
-		v2f x[16];
-		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
-
-		/* x[2 j + v] = element 2 th + v + 1024 j (the window multiply of fft.cl:415-417 rides on the first pass) */
-#pragma unroll
-		for (int j = 0; j < 8; j++) {
-			x[2 * j]     = v2f{ q[j].x, q[j].y };
-			x[2 * j + 1] = v2f{ q[j].z, q[j].w };
-		}
-
-		/* raw IQ of the next spectrum of this tile: shared elements move down, the new ones are requested now */
-		if (g + 1 < p.tile) {
-			const float2 *src = p.iq + (size_t)(t + 1) * p.hop + 2 * th;
-			if (shift == 4) {
-#pragma unroll
-				for (int j = 0; j < 4; j++) q[j] = q[j + 4];
-#pragma unroll
-				for (int j = 4; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
-			} else if (shift == 2) {
-#pragma unroll
-				for (int j = 0; j < 6; j++) q[j] = q[j + 2];
-#pragma unroll
-				for (int j = 6; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
-			} else if (shift == 1) {
-#pragma unroll
-				for (int j = 0; j < 7; j++) q[j] = q[j + 1];
-				q[7] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * 7));
-			} else {
-#pragma unroll
-				for (int j = 0; j < 8; j++) q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + 1024 * j));
-			}
-		}
-
-		/* ---- pass 1: p = 1, items i = 2 th + v, outputs e = 8 i + jj -> slab0 ---- */
-#pragma unroll
-		for (int v = 0; v < 2; v++) {
-			v2f r[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
-			pass8_first(r, wab[v], w8c, two);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				slab0[(v ? st1b : st1a) ^ jj] = r[R8_PERM(jj)];
-		}
-		if (have_prev && !late) K1W_EPI(0, K1W_P1, t - 1);
-		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(0, K1W_P1, t - 1);
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = slab0[rd + 512 * m];		/* item th + 512 v reads e = i + 1024 j = th + 512 (v + 2 j) */
-
-		/* ---- pass 2: p = 8, items i = th + 512 v, k = th & 7 -> slab1 ---- */
-#pragma unroll
-		for (int v = 0; v < 2; v++) {
-			v2f r[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
-			pass8_fma(r, tw8[0], tw8[1], tw8[2], tw8[3], two);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				slab1[(st2 ^ (jj | (8 * (jj & 1)) | (16 * (jj >> 1)))) + 4096 * v] = r[R8_PERM(jj)];
-		}
-		if (have_prev && !late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
-		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = slab1[rd + 512 * m];
-
-		/* ---- pass 3: p = 64, k = th & 63 -> slab0 ---- */
-#pragma unroll
-		for (int v = 0; v < 2; v++) {
-			v2f r[8];
-#pragma unroll
-			for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
-			pass8_fma(r, tw64[0], tw64[1], tw64[2], tw64[3], two);
-#pragma unroll
-			for (int jj = 0; jj < 8; jj++)
-				slab0[(st3 ^ ((8 * jj) & 15)) + 64 * jj + 4096 * v] = r[R8_PERM(jj)];
-		}
-		if (have_prev && !late) K1W_EPI(K1W_P2, 16, t - 1);
-		wg_barrier_lds();
-		if (have_prev && late) K1W_EPI(K1W_P2, 16, t - 1);
-#pragma unroll
-		for (int m = 0; m < 16; m++)
-			x[m] = slab0[rd + 512 * m];
-
-		/* ---- pass 4: p = 512, k = th; its outputs ARE the radix-2 inputs of this thread ---- */
-		{
-			v2f y[16];
-#pragma unroll
-			for (int v = 0; v < 2; v++) {
-				v2f r[8];
-#pragma unroll
-				for (int j = 0; j < 8; j++) r[j] = x[v + 2 * j];
-				pass8_fma(r, tw512[0], tw512[1], tw512[2], tw512[3], two);
-#pragma unroll
-				for (int jj = 0; jj < 8; jj++) y[jj + 8 * v] = r[R8_PERM(jj)];
-			}
-			/* ---- radix 2, p = 4096 (fft.cl:428-458): (jb, jb + 4096), jb = th + 512 c -> columns th + 512 m ---- */
-#pragma unroll
-			for (int c = 0; c < 8; c++) {
-				v2f a = y[c];
-				v2f b = y[c + 8];
-				bf(a, b, twr[c], two);		/* o_pass_radix2_fma */
-				xo[c] = a;
-				xo[c + 8] = b;
-			}
-		}
-
-		if (WRITE_FFT) {
-#pragma unroll
-			for (int m = 0; m < 16; m++)
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + th + TH * m] = xo[m];
-		}
-	}
-	K1W_EPI(0, 16, t0 + p.tile - 1);		/* the tile's last spectrum */
-
-	float2 *pp2 = p.partial + (size_t)tile * N + th;
-#pragma unroll
-	for (int m = 0; m < 16; m++)
-		pp2[TH * m] = make_float2(live[m] * F_HALF_LOG10_2,
-			(vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
-	}
-#undef K1W_EPI
-}
-
-/* Buffer addressing for the 65536-point kernel: every global access of its loop is `scalar base (descriptor) + ONE 32-bit per-lane
+/* Buffer addressing for the 8192- and 65536-point kernels: every global access of their loops is `scalar base (descriptor) + ONE 32-bit per-lane
  * offset + a scalar offset` -- buffer_load / buffer_store ... offen -- where the per-lane offset is fixed for the kernel's lifetime and
  * everything that changes (spectrum, row, column block c) is scalar arithmetic.  With plain pointers the compiler folded the
  * column-block constants into 64-bit per-lane adds (240 of them per spectrum) and spilled.  Arrays addressed this way are < 4 GiB. */
@@ -1559,6 +1255,383 @@ static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_
 {
 	const u2v u = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
 	return v2f{ __uint_as_float(u.x), __uint_as_float(u.y) };
+}
+
+/* X[jj] of a radix-16 pass sits in r[bitrev4(jj)] */
+#define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))
+
+/* ------------------------------------------------------------------------ */
+/* K1 for N = 8192: 512 threads per spectrum, 16 points per thread            */
+/* ------------------------------------------------------------------------ */
+/* The oracle's plan at this length (oracle/fosphor_oracle.c: o_pass_radix16_fma x 3 + o_pass_radix2_fma; no reference behaviour
+ * exists beyond N = 1024): Stockham radix-16 passes p = 1, 16, 256 over 512 work-items of 16 points -- ONE item per thread in every
+ * pass -- and the radix-2 pass p = 4096 of fft.cl:428-458.  Round 5 measured that this kernel's LDS is as busy as its VALUs (three
+ * exchanges of 64 KiB each way per spectrum = 2.2 us per CU next to 2.0 us of VALU issue, and the two add up: profiles/r05_lds.md);
+ * against the radix 8.8.8.8.2 form it replaced this plan moves TWO AND A HALF exchanges through the LDS:
+ *   - exchanges 1 and 2 (behind the passes p = 1 and p = 16) are full: 16 stores, one barrier, 16 loads per thread (two 64 KiB slabs
+ *     used alternately: the barrier behind the stores of an exchange also proves that every thread has finished the loads of the
+ *     exchange before the previous one, i.e. of the slab written next);
+ *   - behind the pass p = 256 item i = k + 256 h holds X3[4096 h + k + 256 m], m < 16, and the radix-2 butterflies pair (jb, jb + 4096):
+ *     thread (h, k) keeps its eight outputs m in [8 h, 8 h + 8), hands the other eight to thread (1 - h, k) through the LDS and does the
+ *     butterflies jb = k + 256 m of its half: 8 stores + 8 loads per thread.  Its columns are k + 2048 h + 256 c + 4096 v, c < 8, v < 2;
+ *   - LDS swizzle phys(e) = e ^ ((e >> 4) & 31) (8-byte elements): the three store patterns (16 i + m; 256 (i >> 4) + (i & 15) + 16 m;
+ *     4096 h + k + 256 m) put the 16 lanes of a ds_write_b64 group into 16 different bank pairs, the lane-contiguous loads e = i + 512 j
+ *     the 32 lanes of a ds_read_b64 group into 32; each store is `per-thread constant ^ compile-time constant`, each load an immediate;
+ *   - everything a thread needs from the tables is fixed per thread and sits in registers: 16 window taps (as the 8 pairs of the first
+ *     pass's stage-A butterflies), 2 x 8 twiddles of the passes p = 16, 256, the 8 of its radix-2 butterflies;
+ *   - the overlap of overlap_cc (overlap_cc_impl.cc:64-79) lives in REGISTERS: a thread holds the raw IQ of elements th + 512 j, j < 16;
+ *     the next window of a tile starts hop = N / R samples later, i.e. 16 / R rows of 512 -- its row j is this window's row j + 16 / R
+ *     of the same thread.  With R = 2 (BASELINE C3) a spectrum costs eight 8-byte loads per thread: every sample of the stream is fetched
+ *     once.  Any hop works (8-byte loads need no 16-byte alignment): odd hops reload all sixteen rows.
+ * One work-group (8 waves, <= 256 registers) per CU.  16-bit bin indices, 2 spectra per dword. */
+/* Work-group barrier for exchanges through LDS only: waits for this wave's LDS operations, not for its outstanding
+ * global loads and stores (__syncthreads() also drains vmcnt, which would park every wave of the work-group behind the
+ * IQ requested for the NEXT spectrum).  Nothing is handed from thread to thread through global memory in these kernels. */
+static __device__ __forceinline__ void wg_barrier_lds()
+{
+#if defined(FOSPHOR_AMD_PROBES) && defined(K1W_NOSYNC)
+	asm volatile("" ::: "memory");		/* timing probe only: results are garbage */
+#else
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+/* K1W_TIMING=1 (probe builds only, tools/k1w_phase_timing.py): s_memtime stamps per phase of the 8192-point kernel's loop, accumulated per
+ * wave (waves 0 and 4 of a work-group: the early and the late one of a SIMD) into K1Params::dbg[(work-group * 2 + slot) * 16 + phase].
+ * Reading the clock waits for the wave's LDS operations (s_memtime answers on lgkmcnt). */
+#ifndef K1W_TIMING
+#define K1W_TIMING 0
+#endif
+/* K1W_PROBE (probe builds, results are garbage: timing only): 1 no LDS stores, 2 no LDS loads, 4 no epilogue, 8 no index stores,
+ * 16 no IQ requests inside the loop */
+#if defined(FOSPHOR_AMD_PROBES) && defined(K1W_PROBE)
+#define K1W_P(b) ((K1W_PROBE) & (b))
+#else
+#define K1W_P(b) 0
+#endif
+#ifndef K1W_READ_FIRST
+#define K1W_READ_FIRST 0		/* (A/B builds) 1: a late wave requests its operands BEFORE its epilogue piece (measured: 1.2 % slower) */
+#endif
+#ifndef K1W_PRIO
+#define K1W_PRIO 1			/* (A/B builds) 1: the passes run at a higher issue priority than the epilogue pieces */
+#endif
+#if K1W_TIMING
+#define K1W_STAMP(i) do { const uint32_t _now = (uint32_t)__builtin_readcyclecounter(); wacc[i] += _now - wprev; wprev = _now; } while (0)
+#else
+#define K1W_STAMP(i) do { } while (0)
+#endif
+
+template <int SHIFT>
+__global__ __launch_bounds__(512, 2)
+void k1w_fft_bin(const K1Params p)
+{
+	constexpr int N = 8192, TH = 512;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	/* two 64 KiB slabs; a spectrum's exchanges use A, B, A (the half one: its first 32 KiB) and the next spectrum's B, A, B */
+	v2f *slab0 = reinterpret_cast<v2f *>(smem_raw);
+	v2f *slab1 = slab0 + N;
+	/* behind the slabs: the exact-bin thresholds (n_bins + 1 <= 513 doubles): the rare path that consults them must not wait behind the IQ
+	 * in flight (a table load through the vector memory path returns in order), and while one wave is in it the other seven wait at the
+	 * next barrier */
+	typedef const __attribute__((address_space(3))) double *lds_cdp;
+	double *thr_g = reinterpret_cast<double *>(slab0 + 2 * N);
+	const lds_cdp thr_l = (lds_cdp)thr_g;
+
+	const int th = threadIdx.x;
+	const int ntiles = p.total / p.tile;
+	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
+	const v2f two = { 2.0f, 2.0f };
+	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
+	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
+	const float top = (float)(bk.nb - 1);
+
+	/* ---- per-thread constants ------------------------------------------------ */
+	const int hh = th >> 8, kk = th & 255;		/* item th = kk + 256 hh of the pass p = 256 */
+	const v2f w16c = twg[p.tw_off[0]], w8c = twg[p.tw_off[0] + 1], w163c = twg[p.tw_off[0] + 2];	/* W16, W8, W16^3: the first pass */
+	v2f wab[8];			/* taps of elements th + 512 j and th + 512 (j + 8): the pair of a first-pass stage-A butterfly */
+	v2f tw16[8], tw256[8];		/* w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3 for k = th & 15, th & 255 */
+	v2f twr[8];			/* radix-2 twiddles k = kk + 256 (8 hh + c) */
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		wab[j] = v2f{ p.win[th + 512 * j], p.win[th + 512 * (j + 8)] };
+		twr[j] = twg[p.tw_off[3] + kk + 256 * (8 * hh + j)];
+	}
+	for (int e = th; e <= p.n_bins && e < 520; e += TH)
+		thr_g[e] = p.thr[e];
+	__syncthreads();
+#pragma unroll
+	for (int n = 0; n < 8; n++) {
+		tw16[n]  = twg[p.tw_off[1] + (th & 15) * 8 + n];
+		tw256[n] = twg[p.tw_off[2] + kk * 8 + n];
+	}
+
+	/* ---- LDS addressing (8-byte elements, phys(e) = e ^ ((e >> 4) & 31)) ----
+	 * loads of every pass: e = th + 512 j -> phys = rd + 512 j
+	 * stores: pass p = 1    e = 16 th + m                          -> st1 ^ m
+	 *         pass p = 16   e = 256 (th >> 4) + (th & 15) + 16 m   -> st2 ^ ((m ^ 16 (m & 1)) | 32 (m >> 1))
+	 *         half exchange (plain layout [m''][th]: lane-contiguous both ways)  stores m'' 512 + th, loads m'' 512 + (th ^ 256) */
+	const int rd  = th ^ ((th >> 4) & 31);
+	const int st1 = (32 * (th >> 1)) | ((16 * (th & 1)) ^ (th & 31));
+	const int st2 = (256 * (th >> 4)) | ((th & 15) ^ (16 * ((th >> 4) & 1)));
+
+	/* SHIFT = 16 / R for hop = N / R, R = 2, 4, 8, 16: the next window's row j is this window's row j + SHIFT of the same thread;
+	 * SHIFT = 16: any other hop, every row is requested again */
+	const uint32_t iq_vo = 8u * (uint32_t)th;		/* element th + 512 j of a window at 8 th + 4096 j (scalar descriptor + one lane offset) */
+	auto ld_iq = [&](__amdgpu_buffer_rsrc_t rs, int j) __attribute__((always_inline)) -> v2f {
+		return bld_v2f<kAuxNT>(rs, iq_vo, 4096u * (uint32_t)j);
+	};
+
+	v2f q[16];			/* raw IQ of the spectrum to be processed next: rows th + 512 j */
+	uint16_t *bins16 = reinterpret_cast<uint16_t *>(p.bins);
+	const uint32_t cb = (uint32_t)kk + 2048u * (uint32_t)hh;	/* column of xo[m]: cb + 256 (m & 7) + 4096 (m >> 3) */
+
+	/* Epilogue of columns [M0, M1) of spectrum tp, whose FFT is in xo: log-power, exact 16-bit bin, live / max, waterfall row
+	 * (display.cl:136-150,161-168).  Per column, nothing carried from column to column: it is cut into three pieces that
+	 * run between the LDS stores of the NEXT spectrum's exchanges and the barrier behind them, i.e. while this wave
+	 * would otherwise wait for the slowest one. */
+#ifndef K1W_P1
+#define K1W_P1 6		/* the three epilogue pieces: columns [0, P1), [P1, P2), [P2, 16) of a thread (A/B builds) */
+#define K1W_P2 11
+#endif
+#define K1W_COL(m) (256 * ((m) & 7) + 4096 * ((m) >> 3))
+#define K1W_EPI(M0, M1, tp) do { \
+		if (K1W_P(4)) break; \
+		if (K1W_PRIO) __builtin_amdgcn_s_setprio(0); \
+		const bool _row = ((tp) >= p.wf_first); \
+		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + cb; \
+		/* index stores: scalar base (SALU) + ONE lane offset + immediate -- the flat form cost a 64-bit VALU add (and its hazard nop) \
+		 * per store.  Byte offset of column cb + K1W_COL(m) in the row of 16-bit pairs: 4 cb + 1024 (m & 7) + 16384 (m >> 3) */ \
+		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2 + ((tp) & 1)); \
+		const uint32_t _bo = 4u * cb; \
+		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
+		_Pragma("unroll") \
+		for (int m = (M0); m < (M1); m++) { \
+			uint32_t ab; \
+			const float rr = bin_fast(xo[m].x, xo[m].y, bk, &_l2[m - (M0)], &ab); \
+			_amb = _amb > ab ? _amb : ab;		/* v_max_u32: NaN / inf order above every finite measure */ \
+			_bn[m - (M0)] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top); \
+		} \
+		/* ONE branch per piece (a compare + exec save + branch per sample cost 9 % of this kernel): rare -- find the samples again \
+		 * and decide them against the exact thresholds */ \
+		if (!K1_DBG_NO_EXACT && _amb > __float_as_uint(bk.amb)) { \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) { \
+				const float v = __builtin_fmaf(bk.A, _l2[m - (M0)], bk.C); \
+				const float a = __builtin_fmaf(__builtin_fabsf(_l2[m - (M0)]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v))); \
+				if (!(a <= bk.amb)) { \
+					float nl2; \
+					_bn[m - (M0)] = bin_exact(xo[m].x, xo[m].y, _l2[m - (M0)], (int)_bn[m - (M0)], thr_l, bk.nb, &nl2); \
+					_l2[m - (M0)] = nl2; \
+				} \
+			} \
+		} \
+		_Pragma("unroll") \
+		for (int m = (M0); m < (M1); m++) { \
+			const float l2v = _l2[m - (M0)]; \
+			const char *_sb = _bdu + 4096 * ((m & 7) >> 2) + 16384 * (m >> 3); \
+			if (!K1W_P(8)) switch (m & 3) { \
+			case 0:  asm volatile("global_store_short %0, %1, %2" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
+			case 1:  asm volatile("global_store_short %0, %1, %2 offset:1024" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
+			case 2:  asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
+			default: asm volatile("global_store_short %0, %1, %2 offset:3072" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
+			} \
+			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
+			vmax[m] = max_f32(vmax[m], l2v); \
+		} \
+		if (_row) {		/* uniform, rare (the last wf_rows spectra of a call): one branch per piece instead of one per sample; the row \
+					 * values are recomputed from the log-powers, which the live / max updates above kept alive anyway */ \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) \
+				_wf[K1W_COL(m)] = _l2[m - (M0)] * F_HALF_LOG10_2; \
+		} \
+		if (K1W_PRIO) __builtin_amdgcn_s_setprio(2); \
+	} while (0)
+
+	if (K1W_PRIO) __builtin_amdgcn_s_setprio(2);
+#if K1W_TIMING
+	uint32_t wacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t wprev = (uint32_t)__builtin_readcyclecounter();
+#endif
+	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	const int t0 = tile * p.tile;
+	float live[16], vmax[16];
+#pragma unroll
+	for (int m = 0; m < 16; m++) { live[m] = 0.0f; vmax[m] = vmax_init; }
+
+	{
+		const __amdgpu_buffer_rsrc_t src = make_rsrc(p.iq + (size_t)t0 * p.hop);
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			q[j] = ld_iq(src, j);
+	}
+
+	v2f xo[16];			/* FFT of the previous spectrum of the tile, its epilogue still to do */
+#pragma unroll
+	for (int m = 0; m < 16; m++) xo[m] = v2f{ 0.0f, 0.0f };
+
+#pragma unroll 1
+	for (int g = 0; g < p.tile; g++) {
+		const int t = t0 + g;
+		const bool have_prev = g > 0;			/* uniform */
+		/* The two waves of a SIMD (waves w and w + 4 of the work-group) run their epilogue pieces on opposite sides of the barrier:
+		 * one computes while the other waits for its LDS loads, instead of all eight moving from LDS to VALU and back together */
+		const int hu = __builtin_amdgcn_readfirstlane(th >> 8);	/* = hh, as a scalar */
+		const bool late = hu != 0;
+		v2f x[16];
+		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
+
+		/* x[j] = element th + 512 j (the window multiply of fft.cl:415-417 rides on the first pass) */
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			x[j] = q[j];
+
+		/* ---- pass 1: p = 1, item th, outputs e = 16 th + m -> slab0.  Before the next spectrum's IQ is requested: the requests then
+		 * land in the registers this pass has just consumed (requested first, they needed sixteen more and a copy at the end of the loop) ---- */
+		K1W_STAMP(0);			/* radix 2 of the previous spectrum, loop overhead, wait for the IQ */
+		pass16_first(x, wab, w16c, w8c, w163c, two);
+		K1W_STAMP(1);
+
+		/* raw IQ of the next spectrum of this tile: shared rows move down, the new ones are requested now.  UNCONDITIONALLY (behind the
+		 * tile's last spectrum: of that spectrum again, unused): a load inside a branch whose result merges with an older value at the
+		 * join makes the compiler wait for it right there */
+		{
+			const int tn = (g + 1 < p.tile) ? t + 1 : t;
+			const __amdgpu_buffer_rsrc_t src = make_rsrc(p.iq + (size_t)tn * p.hop);
+			/* (moves the compiler cannot sink: left to it, they went behind the requests -- whose results then needed registers of their
+			 * own, a copy at the end of the loop and, for that copy, a wait for every store issued in between) */
+#pragma unroll
+			for (int j = 0; j < 16 - SHIFT; j++)
+				asm volatile("v_mov_b64 %0, %1" : "=v"(q[j]) : "v"(q[j + SHIFT]));
+#pragma unroll
+			for (int j = 16 - SHIFT; j < 16; j++) if (!K1W_P(16)) q[j] = ld_iq(src, j);
+		}
+
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			if (!K1W_P(1)) slab0[st1 ^ m] = x[R16_PERM(m)];
+		if (have_prev && !late) K1W_EPI(0, K1W_P1, t - 1);
+		K1W_STAMP(2);			/* IQ requests, stores (until done), early piece */
+		wg_barrier_lds();
+		K1W_STAMP(3);			/* barrier */
+#if K1W_READ_FIRST
+		/* the reads are requested BEFORE the late piece: a late wave's piece then runs while its operands travel (and while the early
+		 * wave of its SIMD, whose reads were requested at the same moment, has nothing to compute yet) */
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			if (!K1W_P(2)) x[j] = slab0[rd + 512 * j];
+		if (have_prev && late) K1W_EPI(0, K1W_P1, t - 1);
+		K1W_STAMP(4);			/* late piece */
+#else
+		if (have_prev && late) K1W_EPI(0, K1W_P1, t - 1);
+		K1W_STAMP(4);			/* late piece */
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			if (!K1W_P(2)) x[j] = slab0[rd + 512 * j];
+#endif
+		K1W_STAMP(5);			/* reads (until all have arrived) */
+
+		/* ---- pass 2: p = 16, k = th & 15, outputs e = 256 (th >> 4) + (th & 15) + 16 m -> slab1 ---- */
+		pass16_ab(x, tw16[0], tw16[1], two);
+		pass16_cd(x, tw16[2], tw16[3], tw16[4], tw16[5], tw16[6], tw16[7], two);
+		K1W_STAMP(6);			/* pass 2 */
+#pragma unroll
+		for (int m = 0; m < 16; m++)
+			if (!K1W_P(1)) slab1[st2 ^ ((m ^ (16 * (m & 1))) | (32 * (m >> 1)))] = x[R16_PERM(m)];
+		if (have_prev && !late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
+		K1W_STAMP(7);
+		wg_barrier_lds();
+		K1W_STAMP(8);
+#if K1W_READ_FIRST
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			if (!K1W_P(2)) x[j] = slab1[rd + 512 * j];
+		if (have_prev && late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
+		K1W_STAMP(9);
+#else
+		if (have_prev && late) K1W_EPI(K1W_P1, K1W_P2, t - 1);
+		K1W_STAMP(9);
+#pragma unroll
+		for (int j = 0; j < 16; j++)
+			if (!K1W_P(2)) x[j] = slab1[rd + 512 * j];
+#endif
+		K1W_STAMP(10);
+
+		/* ---- pass 3: p = 256, k = kk: X3[4096 hh + kk + 256 m] = x[R16_PERM(m)]; the half this thread's butterflies do not need goes to
+		 * thread th ^ 256 through slab0 ([m''][th]: m'' = m - 8 (1 - hh)) ---- */
+		pass16_ab(x, tw256[0], tw256[1], two);
+		pass16_cd(x, tw256[2], tw256[3], tw256[4], tw256[5], tw256[6], tw256[7], two);
+		K1W_STAMP(11);			/* pass 3 */
+		if (hu == 0) {			/* uniform per wave (waves 0-3 / 4-7): a scalar branch */
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				if (!K1W_P(1)) slab0[512 * c + th] = x[R16_PERM(8 + c)];
+		} else {
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				if (!K1W_P(1)) slab0[512 * c + th] = x[R16_PERM(c)];
+		}
+		if (have_prev && !late) K1W_EPI(K1W_P2, 16, t - 1);
+		K1W_STAMP(12);
+		wg_barrier_lds();
+		K1W_STAMP(13);
+		/* ---- radix 2, p = 4096 (fft.cl:428-458; o_pass_radix2_fma): (jb, jb + 4096), jb = kk + 256 (8 hh + c) ->
+		 * xo[c] = X[jb], xo[c + 8] = X[jb + 4096] ---- */
+		{
+			v2f o[8];
+#if K1W_READ_FIRST
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				o[c] = K1W_P(2) ? x[c] : slab0[512 * c + (th ^ 256)];
+			if (have_prev && late) K1W_EPI(K1W_P2, 16, t - 1);
+			K1W_STAMP(14);
+#else
+			if (have_prev && late) K1W_EPI(K1W_P2, 16, t - 1);
+			K1W_STAMP(14);
+#pragma unroll
+			for (int c = 0; c < 8; c++)
+				o[c] = K1W_P(2) ? x[c] : slab0[512 * c + (th ^ 256)];
+#endif
+			K1W_STAMP(15);
+			if (hu == 0) {			/* X3[jb] is this item's output m = c, X3[jb + 4096] item th + 256's */
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					v2f a = x[R16_PERM(c)], b = o[c];
+					bf(a, b, twr[c], two);
+					xo[c] = a; xo[c + 8] = b;
+				}
+			} else {			/* X3[jb] is item th - 256's output m = 8 + c, X3[jb + 4096] this item's */
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					v2f a = o[c], b = x[R16_PERM(8 + c)];
+					bf(a, b, twr[c], two);
+					xo[c] = a; xo[c + 8] = b;
+				}
+			}
+		}
+
+		if (p.fft_out) {		/* (tests) */
+#pragma unroll
+			for (int m = 0; m < 16; m++)
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + cb + K1W_COL(m)] = xo[m];
+		}
+	}
+	K1W_EPI(0, 16, t0 + p.tile - 1);		/* the tile's last spectrum */
+
+	float2 *pp2 = p.partial + (size_t)tile * N + cb;
+#pragma unroll
+	for (int m = 0; m < 16; m++)
+		pp2[K1W_COL(m)] = make_float2(live[m] * F_HALF_LOG10_2,
+			(vmax[m] == vmax_init) ? -1000.0f : vmax[m] * F_HALF_LOG10_2);
+	}
+#if K1W_TIMING
+	if (p.dbg && (th & 255) == 0) {
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			p.dbg[((size_t)blockIdx.x * 2 + (th >> 8)) * 16 + i] = wacc[i];
+	}
+#endif
+#undef K1W_EPI
+#undef K1W_COL
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1629,8 +1702,6 @@ static __device__ __forceinline__ v2f bld_v2f(__amdgpu_buffer_rsrc_t rs, uint32_
 #else
 #define K1H_STAMP(i) do { } while (0)
 #endif
-/* X[jj] of a radix-16 pass sits in r[bitrev4(jj)] */
-#define R16_PERM(jj) ((((jj) & 1) << 3) | (((jj) & 2) << 1) | (((jj) & 4) >> 1) | (((jj) & 8) >> 3))
 
 constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [residue 4][jj 16][a 16], rows padded to 17 */
 constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
@@ -2173,48 +2244,26 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		}
 		if (p.log2n != 13)
 			return hipErrorInvalidValue;
-		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); needs 16-byte aligned
-		 * windows (even hop).  FOSPHOR_AMD_K1W=0: the general kernel. */
-		if (!p.k1w_off && !(p.hop & 1)) {
-			constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
-			static bool attr_w = false;
-			if (!attr_w) {
-				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1w_fft_bin<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
-				if (e == hipSuccess)
-					e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1w_fft_bin<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
+		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); any hop */
+		constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
+		typedef void (*k1w_fn)(const K1Params);
+		static const k1w_fn fns[5] = { k1w_fft_bin<8>, k1w_fft_bin<4>, k1w_fft_bin<2>, k1w_fft_bin<1>, k1w_fft_bin<16> };
+		if (!attr_set) {
+			for (int i = 0; i < 5; i++) {
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
 				if (e != hipSuccess)
 					return e;
-				attr_w = true;
 			}
-			/* one 8-wave work-group per CU -- or per CU of the share the host leaves to this kernel (K1Params.cus: the count and
-			 * merge kernels of the previous launch run on the rest) */
-			const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
-			const int cus = (p.cus > 0 && p.cus < all_cus && tiles % p.cus == 0) ? p.cus : all_cus;
-			const int bw = tiles < cus ? tiles : cus;
-			if (p.fft_out)
-				hipLaunchKernelGGL(k1w_fft_bin<true>, dim3(bw), dim3(512), ldsw, s, p);
-			else
-				hipLaunchKernelGGL(k1w_fft_bin<false>, dim3(bw), dim3(512), ldsw, s, p);
-			return hipGetLastError();
-		}
-		constexpr int N = 8192;
-		constexpr int lds = (N + ((N / 2 - 8) / 7) * 4 + N / 2 + 1) * 8 + N * 4;	/* exchange slab + the long plan's twiddle table + window */
-		const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
-		int blocks = tiles < all_cus ? tiles : all_cus;		/* one work-group (16 waves, 128 VGPRs) per CU */
-		if (!attr_set) {
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, false>),
-			                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-			if (e == hipSuccess)
-				e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1big_fft_bin<13, true>),
-				                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-			if (e != hipSuccess)
-				return e;
 			attr_set = true;
 		}
-		if (p.fft_out)
-			hipLaunchKernelGGL((k1big_fft_bin<13, true>), dim3(blocks), dim3(N / 8), lds, s, p);
-		else
-			hipLaunchKernelGGL((k1big_fft_bin<13, false>), dim3(blocks), dim3(N / 8), lds, s, p);
+		/* rows of 512 samples the next window of a tile shares with this one: hop = 8192 / R, R = 2, 4, 8, 16; any other hop: none */
+		const int which = (p.hop == 4096) ? 0 : (p.hop == 2048) ? 1 : (p.hop == 1024) ? 2 : (p.hop == 512) ? 3 : 4;
+		/* one 8-wave work-group per CU -- or per CU of the share the host leaves to this kernel (K1Params.cus: the count and
+		 * merge kernels of the previous launch run on the rest) */
+		const int all_cus = p.n_cus > 0 ? p.n_cus : 256;
+		const int cus = (p.cus > 0 && p.cus < all_cus && tiles % p.cus == 0) ? p.cus : all_cus;
+		const int bw = tiles < cus ? tiles : cus;
+		hipLaunchKernelGGL(fns[which], dim3(bw), dim3(512), ldsw, s, p);
 		return hipGetLastError();
 	}
 	if (p.variant == 2) {

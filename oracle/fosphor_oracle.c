@@ -144,8 +144,9 @@ static void o_pass_radix4(const cf *src, cf *dst, int n, int p)
  * The reference has ONE FFT length, 1024 (fft.cl:397-466), and no reference behaviour exists for the lengths BASELINE
  * configs C3 / C5 name.  The plans below are THIS BUILD'S OWN CHOICE, restated here operation for
  * operation so that the GPU kernels can be checked bit for bit.  They keep the reference's data flow -- Stockham passes with
- * the indexing of fft.cl:278-350 (radix 8, p = 1, 8, 64, 512, then the radix-2 pass of fft.cl:428-458 at N = 8192; the same
- * with 16 in the place of 8, p = 1, 16, 256, 4096, at N = 65536), twiddle angles from the reference's expression
+ * the indexing of fft.cl:278-350 with 16 in the place of 8: radix 16, p = 1, 16, 256 and then the radix-2 pass of fft.cl:428-458
+ * (p = 4096) at N = 8192 (two LDS exchanges and a half instead of the three of 8.8.8.8.2: the GPU kernel's LDS is as busy as its
+ * VALUs); p = 1, 16, 256, 4096 at N = 65536 --, twiddle angles from the reference's expression
  * -pi k / ((R/2) p) (fft.cl:286-297) through the pinned sin / cos -- and change the ARITHMETIC INSIDE A PASS to what a
  * fused-multiply-add machine does best: the radix-R butterfly is log2(R) radix-2 stages in decimation-in-time form whose
  * twiddles sit ON the butterflies,
@@ -350,7 +351,7 @@ static void o_fft_one(int log2n, const cf *in, cf *out, const float *win, cf *sc
 
 	if (log2n == 13 || log2n == 16) {
 		/* this build's plans for the long lengths (see o_pass_radix8_fma): the window rides on the first pass */
-		const int lr = (log2n == 16) ? 4 : 3;
+		const int lr = 4;		/* radix-16 passes p = 1, 16, 256 (, 4096); N = 8192 ends with the radix-2 pass p = 4096 */
 		const cf *src = in;
 		p = 1;
 		for (done = 0; done + lr <= log2n; done += lr) {

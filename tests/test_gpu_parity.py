@@ -1294,19 +1294,18 @@ def test_fft8192_bit_exact(amd, torch_cuda, oracle_built):
     f.close()
 
 
-@pytest.mark.parametrize("overlap,tile,k1w", [(2, None, "1"), (2, "32", "1"), (2, "64", "1"), (4, "32", "1"), (8, "64", "1"),
-                                              (16, "32", "1"), (2, "64", "0"), (4, None, "0")])
-def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overlap, tile, k1w):
+@pytest.mark.parametrize("overlap,tile", [(2, None), (2, "32"), (2, "64"), (4, "32"), (8, "64"), (16, "32"), (4, None),
+                                          (1, "32"), (32, "32"), (8192, None)])
+def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overlap, tile):
     """8192-point FFT, 512 bins, overlap_cc fused into the read, two launches with state carry-over.  The overlapped part of a
-    window is reused from registers through one branch per ratio (overlap 2 / 4 / 8; 16 reloads everything), at the tile
-    lengths the real C3 launch uses (32, 64) as well as the short ones small launches pick, and through the general kernel
-    (FOSPHOR_AMD_K1W=0, what odd hops fall back to)."""
+    window is reused from registers through one branch per ratio (overlap 2 / 4 / 8 / 16; anything else -- no overlap, 32, the odd
+    hop of overlap 8192 -- reloads every row), at the tile lengths the real C3 launch uses (32, 64) as well as the short ones
+    small launches pick."""
     torch = torch_cuda
     n, nb = 8192, 512
     hop = n // overlap
     if tile:
         monkeypatch.setenv("FOSPHOR_AMD_TILE", tile)
-    monkeypatch.setenv("FOSPHOR_AMD_K1W", k1w)
     f = amd.Fosphor(fft_len_log=13, n_bins=nb, max_spectra=128)
     o = Oracle(fft_len_log=13, n_bins=nb)
     assert f.histo_scale == o.histo_scale and f.histo_offset == o.histo_offset
