@@ -119,22 +119,49 @@ static __device__ __forceinline__ void dft8(v2f (&r)[8], v2f s12)
  * products + 28 for dft8), 96 per 16 points instead of 133, and 4 / 8 twiddles per item instead of 7 / 15.  Every operation is one
  * IEEE operation here and one fmaf / add / multiply there. */
 
-/* o_bf: u = (a.x - b.y T.y, a.y + b.x T.y);  a' = (u.x + b.x T.x, u.y + b.y T.x);  b' = 2 a - a' */
+/* o_bf: u = (a.x - b.y T.y, a.y + b.x T.y);  a' = (u.x + b.x T.x, u.y + b.y T.x);  b' = 2 a - a'
+ * SC (the 8192-point kernel, which has no vector register to spare): `two` = (2, 2) travels in a scalar register pair -- a packed operation
+ * takes one scalar source --, and so do the twiddles that are the same for every thread (bf_s, bf_mj_s: W8, W16, W16^3 of a first pass). */
+template <bool SC = false>
 static __device__ __forceinline__ void bf(v2f &a, v2f &b, v2f t, v2f two)
 {
 	v2f u, pa, nb;
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(b), "v"(t), "v"(a));
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa) : "v"(b), "v"(t), "v"(u));
-	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
+	if (SC) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "s"(two), "v"(pa));
+	else    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
 	a = pa; b = nb;
 }
 /* o_bf_mj (T := -j T): u = (a.x + b.x T.y, a.y + b.y T.y);  a' = (u.x + b.y T.x, u.y - b.x T.x);  b' = 2 a - a' */
+template <bool SC = false>
 static __device__ __forceinline__ void bf_mj(v2f &a, v2f &b, v2f t, v2f two)
 {
 	v2f u, pa, nb;
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(b), "v"(t), "v"(a));
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(pa) : "v"(b), "v"(t), "v"(u));
-	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
+	if (SC) asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "s"(two), "v"(pa));
+	else    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "v"(two), "v"(pa));
+	a = pa; b = nb;
+}
+/* ... with a twiddle that is the same for every thread */
+template <bool SC = false>
+static __device__ __forceinline__ void bf_s(v2f &a, v2f &b, v2f t, v2f two)
+{
+	if (!SC) { bf<false>(a, b, t, two); return; }
+	v2f u, pa, nb;
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u) : "v"(b), "s"(t), "v"(a));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa) : "v"(b), "s"(t), "v"(u));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "s"(two), "v"(pa));
+	a = pa; b = nb;
+}
+template <bool SC = false>
+static __device__ __forceinline__ void bf_mj_s(v2f &a, v2f &b, v2f t, v2f two)
+{
+	if (!SC) { bf_mj<false>(a, b, t, two); return; }
+	v2f u, pa, nb;
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(b), "s"(t), "v"(a));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(pa) : "v"(b), "s"(t), "v"(u));
+	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "s"(two), "v"(pa));
 	a = pa; b = nb;
 }
 /* o_bf_win, stage A of the first pass: m = a wab.x;  a' = fma(b, wab.y, m);  b' = fma(-b, wab.y, m)   (wab = the two window taps) */
@@ -169,30 +196,33 @@ static __device__ __forceinline__ void pass8_first(v2f (&r)[8], const v2f (&wab)
 /* o_pass_radix16_fma, p > 1, in two halves (the 65536-point kernel runs other work between them):
  * stages A, B: t8 = w^8, t4 = w^4;  stages C, D: t2 = w^2, t2w = w^2 W8, t1 = w, t1a = w W16, t1b = w W8, t1c = w W16^3.
  * X[m] is left in r[bitrev4(m)] (R16_PERM). */
+template <bool SC = false>
 static __device__ __forceinline__ void pass16_ab(v2f (&r)[16], v2f t8, v2f t4, v2f two)
 {
 #pragma unroll
 	for (int j = 0; j < 8; j++)
-		bf(r[j], r[j + 8], t8, two);
+		bf<SC>(r[j], r[j + 8], t8, two);
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
-		bf(r[j], r[j + 4], t4, two);
-		bf_mj(r[8 + j], r[12 + j], t4, two);
+		bf<SC>(r[j], r[j + 4], t4, two);
+		bf_mj<SC>(r[8 + j], r[12 + j], t4, two);
 	}
 }
+template <bool SC = false>
 static __device__ __forceinline__ void pass16_cd(v2f (&r)[16], v2f t2, v2f t2w, v2f t1, v2f t1a, v2f t1b, v2f t1c, v2f two)
 {
 #pragma unroll
 	for (int j = 0; j < 2; j++) {
-		bf(r[j], r[j + 2], t2, two);
-		bf_mj(r[4 + j], r[6 + j], t2, two);
-		bf(r[8 + j], r[10 + j], t2w, two);
-		bf_mj(r[12 + j], r[14 + j], t2w, two);
+		bf<SC>(r[j], r[j + 2], t2, two);
+		bf_mj<SC>(r[4 + j], r[6 + j], t2, two);
+		bf<SC>(r[8 + j], r[10 + j], t2w, two);
+		bf_mj<SC>(r[12 + j], r[14 + j], t2w, two);
 	}
-	bf(r[0], r[1], t1, two);   bf_mj(r[2], r[3], t1, two);    bf(r[4], r[5], t1b, two);   bf_mj(r[6], r[7], t1b, two);
-	bf(r[8], r[9], t1a, two);  bf_mj(r[10], r[11], t1a, two); bf(r[12], r[13], t1c, two); bf_mj(r[14], r[15], t1c, two);
+	bf<SC>(r[0], r[1], t1, two);   bf_mj<SC>(r[2], r[3], t1, two);    bf<SC>(r[4], r[5], t1b, two);   bf_mj<SC>(r[6], r[7], t1b, two);
+	bf<SC>(r[8], r[9], t1a, two);  bf_mj<SC>(r[10], r[11], t1a, two); bf<SC>(r[12], r[13], t1c, two); bf_mj<SC>(r[14], r[15], t1c, two);
 }
 /* ... p = 1: the window on stage A (wab[j] = taps of r[j], r[j + 8]); w16 = W16, w8 = W8, w163 = W16^3 */
+template <bool SC = false>
 static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wab)[8], v2f w16, v2f w8, v2f w163, v2f two)
 {
 #pragma unroll
@@ -207,11 +237,11 @@ static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wa
 	for (int j = 0; j < 2; j++) {
 		DFT2(r[j], r[j + 2]);
 		DFT2_MJ(r[4 + j], r[6 + j]);
-		bf(r[8 + j], r[10 + j], w8, two);
-		bf_mj(r[12 + j], r[14 + j], w8, two);
+		bf_s<SC>(r[8 + j], r[10 + j], w8, two);
+		bf_mj_s<SC>(r[12 + j], r[14 + j], w8, two);
 	}
-	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);           bf(r[4], r[5], w8, two);     bf_mj(r[6], r[7], w8, two);
-	bf(r[8], r[9], w16, two);  bf_mj(r[10], r[11], w16, two); bf(r[12], r[13], w163, two); bf_mj(r[14], r[15], w163, two);
+	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);           bf_s<SC>(r[4], r[5], w8, two);   bf_mj_s<SC>(r[6], r[7], w8, two);
+	bf_s<SC>(r[8], r[9], w16, two); bf_mj_s<SC>(r[10], r[11], w16, two); bf_s<SC>(r[12], r[13], w163, two); bf_mj_s<SC>(r[14], r[15], w163, two);
 }
 
 /* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
@@ -1399,9 +1429,12 @@ void k1w_fft_bin(const K1Params p)
 		if (K1W_PRIO) __builtin_amdgcn_s_setprio(0); \
 		const bool _row = ((tp) >= p.wf_first); \
 		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + cb; \
-		/* index stores: scalar base (SALU) + ONE lane offset + immediate -- the flat form cost a 64-bit VALU add (and its hazard nop) \
-		 * per store.  Byte offset of column cb + K1W_COL(m) in the row of 16-bit pairs: 4 cb + 1024 (m & 7) + 16384 (m >> 3) */ \
-		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2 + ((tp) & 1)); \
+		/* index stores: one dword per column and PAIR of spectra (the layout the count kernel reads: 16-bit indices, two spectra per dword). \
+		 * A vector-memory instruction costs a CU 11-17 cycles whatever it carries (tools/ubench/vmem_rate.hip: 16.5 for 64 strided shorts, \
+		 * 10.8 for 64 dwords), and with a 16-bit store per sample the index stores were a quarter of this kernel's time: the indices of an \
+		 * even spectrum wait in eight registers for the odd one's (tiles are even: launch_k1).  Scalar base (SALU) + ONE lane offset + \
+		 * immediate; byte offset of column cb + K1W_COL(m) in the row: 4 cb + 1024 (m & 7) + 16384 (m >> 3) */ \
+		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2); \
 		const uint32_t _bo = 4u * cb; \
 		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
 		_Pragma("unroll") \
@@ -1425,18 +1458,27 @@ void k1w_fft_bin(const K1Params p)
 				} \
 			} \
 		} \
+		if (!((tp) & 1)) {		/* (uniform: ONE branch per piece) even spectrum: keep the indices, two columns per register */ \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) \
+				held[m >> 1] = (m & 1) ? __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 1], 0x05040100u) : _bn[m - (M0)]; \
+		} else if (!K1W_P(8)) {		/* odd spectrum: the dword of both */ \
+			_Pragma("unroll") \
+			for (int m = (M0); m < (M1); m++) { \
+				const char *_sb = _bdu + 4096 * ((m & 7) >> 2) + 16384 * (m >> 3); \
+				const uint32_t _d = __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 1], (m & 1) ? 0x05040302u : 0x05040100u); \
+				switch (m & 3) { \
+				case 0:  asm volatile("global_store_dword %0, %1, %2" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 1:  asm volatile("global_store_dword %0, %1, %2 offset:1024" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 2:  asm volatile("global_store_dword %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
+				default: asm volatile("global_store_dword %0, %1, %2 offset:3072" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
+				} \
+			} \
+		} \
 		_Pragma("unroll") \
 		for (int m = (M0); m < (M1); m++) { \
-			const float l2v = _l2[m - (M0)]; \
-			const char *_sb = _bdu + 4096 * ((m & 7) >> 2) + 16384 * (m >> 3); \
-			if (!K1W_P(8)) switch (m & 3) { \
-			case 0:  asm volatile("global_store_short %0, %1, %2" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
-			case 1:  asm volatile("global_store_short %0, %1, %2 offset:1024" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
-			case 2:  asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
-			default: asm volatile("global_store_short %0, %1, %2 offset:3072" :: "v"(_bo), "v"(_bn[m - (M0)]), "s"(_sb) : "memory"); break; \
-			} \
-			live[m] = __builtin_fmaf(live[m], p.w, l2v); \
-			vmax[m] = max_f32(vmax[m], l2v); \
+			live[m] = __builtin_fmaf(live[m], p.w, _l2[m - (M0)]); \
+			vmax[m] = max_f32(vmax[m], _l2[m - (M0)]); \
 		} \
 		if (_row) {		/* uniform, rare (the last wf_rows spectra of a call): one branch per piece instead of one per sample; the row \
 					 * values are recomputed from the log-powers, which the live / max updates above kept alive anyway */ \
@@ -1455,6 +1497,7 @@ void k1w_fft_bin(const K1Params p)
 	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 	const int t0 = tile * p.tile;
 	float live[16], vmax[16];
+	uint32_t held[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };	/* bin indices of the tile's last even spectrum, two columns per register */
 #pragma unroll
 	for (int m = 0; m < 16; m++) { live[m] = 0.0f; vmax[m] = vmax_init; }
 
@@ -1481,14 +1524,22 @@ void k1w_fft_bin(const K1Params p)
 		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
 
 		/* x[j] = element th + 512 j (the window multiply of fft.cl:415-417 rides on the first pass) */
+		/* ---- pass 1: p = 1, item th, outputs e = 16 th + m -> slab0.  Before the next spectrum's IQ is requested: the requests then
+		 * land in the registers this pass has just consumed (requested first, they needed sixteen more and a copy at the end of the loop) ---- */
+		/* the IQ requested one iteration ago has arrived once at most the index stores issued BEHIND the requests are outstanding: the
+		 * sixteen of an odd spectrum's epilogue, which ran in the previous iteration if that one's g was even and >= 2 (more, if waterfall
+		 * rows or fft_out went out as well: the wait is then longer than needed, not shorter) */
+#define K1W_Q16 "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), \
+		"+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15])
+		/* (ONE statement, the choice inside it: two statements under an if made the compiler copy q -- before the wait) */
+		asm volatile("s_cmp_eq_u32 %16, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(16)\n\ts_branch 2f\n1:\ts_waitcnt vmcnt(0)\n2:"
+		             : K1W_Q16 : "s"(__builtin_amdgcn_readfirstlane((!K1W_P(8) && (g & 1) && g >= 3) ? 1 : 0)) : "scc");
+#undef K1W_Q16
 #pragma unroll
 		for (int j = 0; j < 16; j++)
 			x[j] = q[j];
-
-		/* ---- pass 1: p = 1, item th, outputs e = 16 th + m -> slab0.  Before the next spectrum's IQ is requested: the requests then
-		 * land in the registers this pass has just consumed (requested first, they needed sixteen more and a copy at the end of the loop) ---- */
 		K1W_STAMP(0);			/* radix 2 of the previous spectrum, loop overhead, wait for the IQ */
-		pass16_first(x, wab, w16c, w8c, w163c, two);
+		pass16_first<true>(x, wab, w16c, w8c, w163c, two);
 		K1W_STAMP(1);
 
 		/* raw IQ of the next spectrum of this tile: shared rows move down, the new ones are requested now.  UNCONDITIONALLY (behind the
@@ -1502,8 +1553,14 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 			for (int j = 0; j < 16 - SHIFT; j++)
 				asm volatile("v_mov_b64 %0, %1" : "=v"(q[j]) : "v"(q[j + SHIFT]));
+			/* The requests are made by hand, and so is the wait for them at the top of the next iteration: loads and stores leave the
+			 * vmcnt queue IN ORDER, and the wait the compiler places for loads it knows about -- vmcnt(0) -- also sat through the
+			 * acknowledgement of every index store issued since (a third of this kernel's time: probe builds without the stores / without
+			 * the requests, profiles/r05_c3.md) */
 #pragma unroll
-			for (int j = 16 - SHIFT; j < 16; j++) if (!K1W_P(16)) q[j] = ld_iq(src, j);
+			for (int j = 16 - SHIFT; j < 16; j++)
+				if (!K1W_P(16))
+					asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen nt" : "=v"(q[j]) : "v"(iq_vo), "s"(src), "s"(4096u * (uint32_t)j));
 		}
 
 #pragma unroll
@@ -1531,8 +1588,8 @@ void k1w_fft_bin(const K1Params p)
 		K1W_STAMP(5);			/* reads (until all have arrived) */
 
 		/* ---- pass 2: p = 16, k = th & 15, outputs e = 256 (th >> 4) + (th & 15) + 16 m -> slab1 ---- */
-		pass16_ab(x, tw16[0], tw16[1], two);
-		pass16_cd(x, tw16[2], tw16[3], tw16[4], tw16[5], tw16[6], tw16[7], two);
+		pass16_ab<true>(x, tw16[0], tw16[1], two);
+		pass16_cd<true>(x, tw16[2], tw16[3], tw16[4], tw16[5], tw16[6], tw16[7], two);
 		K1W_STAMP(6);			/* pass 2 */
 #pragma unroll
 		for (int m = 0; m < 16; m++)
@@ -1558,8 +1615,8 @@ void k1w_fft_bin(const K1Params p)
 
 		/* ---- pass 3: p = 256, k = kk: X3[4096 hh + kk + 256 m] = x[R16_PERM(m)]; the half this thread's butterflies do not need goes to
 		 * thread th ^ 256 through slab0 ([m''][th]: m'' = m - 8 (1 - hh)) ---- */
-		pass16_ab(x, tw256[0], tw256[1], two);
-		pass16_cd(x, tw256[2], tw256[3], tw256[4], tw256[5], tw256[6], tw256[7], two);
+		pass16_ab<true>(x, tw256[0], tw256[1], two);
+		pass16_cd<true>(x, tw256[2], tw256[3], tw256[4], tw256[5], tw256[6], tw256[7], two);
 		K1W_STAMP(11);			/* pass 3 */
 		if (hu == 0) {			/* uniform per wave (waves 0-3 / 4-7): a scalar branch */
 #pragma unroll
@@ -1596,14 +1653,14 @@ void k1w_fft_bin(const K1Params p)
 #pragma unroll
 				for (int c = 0; c < 8; c++) {
 					v2f a = x[R16_PERM(c)], b = o[c];
-					bf(a, b, twr[c], two);
+					bf<true>(a, b, twr[c], two);
 					xo[c] = a; xo[c + 8] = b;
 				}
 			} else {			/* X3[jb] is item th - 256's output m = 8 + c, X3[jb + 4096] this item's */
 #pragma unroll
 				for (int c = 0; c < 8; c++) {
 					v2f a = o[c], b = x[R16_PERM(8 + c)];
-					bf(a, b, twr[c], two);
+					bf<true>(a, b, twr[c], two);
 					xo[c] = a; xo[c + 8] = b;
 				}
 			}
@@ -1615,6 +1672,9 @@ void k1w_fft_bin(const K1Params p)
 				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + cb + K1W_COL(m)] = xo[m];
 		}
 	}
+	/* the last iteration's requests (made unconditionally, see above) still own their registers: nothing may reuse them before they have landed */
+	asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]),
+	             "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
 	K1W_EPI(0, 16, t0 + p.tile - 1);		/* the tile's last spectrum */
 
 	float2 *pp2 = p.partial + (size_t)tile * N + cb;
@@ -2242,7 +2302,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 				hipLaunchKernelGGL((k1big_fft_bin<10, false>), dim3(blocks), dim3(N / 8), lds, s, p);
 			return hipGetLastError();
 		}
-		if (p.log2n != 13)
+		if (p.log2n != 13 || (p.tile & 1))		/* (the kernel pairs the index rows of spectra 2 u, 2 u + 1 inside a tile) */
 			return hipErrorInvalidValue;
 		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); any hop */
 		constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
