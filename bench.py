@@ -510,11 +510,8 @@ def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
                     break
             if traffic:
                 break
-        # (the launch condition of launch_k1: k1w_fft_bin unless FOSPHOR_AMD_K1W=0 or the hop is odd)
-        k1w = os.environ.get("FOSPHOR_AMD_K1W", "1")[:1] != "0" and not (hop & 1)
         k1_name = {10: "k1_fft_bin (K1, one wave per spectrum)",
-                   13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, FMA butterflies, overlap reused from registers)" if k1w else
-                       "k1big_fft_bin<13> (K1, N/8 threads per spectrum)",
+                   13: "k1w_fft_bin (K1, 512 threads x 16 points per spectrum, radix 16.16.16.2 of FMA butterflies, overlap reused from registers)",
                    16: "k1h_fused (K1, radix-16 plan of FMA butterflies: two 256-point levels in one kernel, intermediate in the XCD's L2)"}[cfg["log2n"]]
         if cfg["log2n"] == 10 and os.environ.get("FOSPHOR_AMD_K1", "1")[:1] == "2":
             k1_name = "k1v2_fft_bin (K1, two waves per spectrum)"

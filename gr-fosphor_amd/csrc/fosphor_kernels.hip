@@ -112,7 +112,7 @@ static __device__ __forceinline__ void dft8(v2f (&r)[8], v2f s12)
 /* The long plans (N = 8192, 65536): twiddles on the butterflies, fused multiply-adds */
 /* ------------------------------------------------------------------------ */
 /* No reference behaviour exists at these lengths; the plan is this build's and the oracle restates it operation for operation
- * (oracle/fosphor_oracle.c: o_bf, o_bf_mj, o_bf_win, o_pass_radix8_fma, o_pass_radix16_fma, o_pass_radix2_fma -- the derivation is
+ * (oracle/fosphor_oracle.c: o_bf, o_bf_mj, o_bf_win, o_pass_radix16_fma, o_pass_radix2_fma -- the derivation is
  * written there).  A radix-R pass is log2 R radix-2 stages in decimation-in-time form, every butterfly
  *      a' = a + T b  (two v_pk_fma_f32)      b' = 2 a - a'  (one)
  * with T the twiddle of its stage and position: 36 packed operations per 8 points and pass instead of 49 (21 for seven complex
@@ -172,25 +172,6 @@ static __device__ __forceinline__ void bf_win(v2f &a, v2f &b, v2f wab)
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(pa) : "v"(b), "v"(wab), "v"(m));
 	asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(nb) : "v"(b), "v"(wab), "v"(m));
 	a = pa; b = nb;
-}
-
-/* o_pass_radix8_fma, p > 1: t4 = w^4, t2 = w^2, t1 = w, t1w = w W8.  X[m] is left in r[bitrev3(m)] like dft8 leaves it. */
-static __device__ __forceinline__ void pass8_fma(v2f (&r)[8], v2f t4, v2f t2, v2f t1, v2f t1w, v2f two)
-{
-#pragma unroll
-	for (int j = 0; j < 4; j++)
-		bf(r[j], r[j + 4], t4, two);
-	bf(r[0], r[2], t2, two); bf(r[1], r[3], t2, two); bf_mj(r[4], r[6], t2, two); bf_mj(r[5], r[7], t2, two);
-	bf(r[0], r[1], t1, two); bf_mj(r[2], r[3], t1, two); bf(r[4], r[5], t1w, two); bf_mj(r[6], r[7], t1w, two);
-}
-/* ... p = 1 (w = 1): the window on stage A (wab[j] = taps of r[j], r[j + 4]), plain sums where T is 1 or -j */
-static __device__ __forceinline__ void pass8_first(v2f (&r)[8], const v2f (&wab)[4], v2f w8, v2f two)
-{
-#pragma unroll
-	for (int j = 0; j < 4; j++)
-		bf_win(r[j], r[j + 4], wab[j]);
-	DFT2(r[0], r[2]); DFT2(r[1], r[3]); DFT2_MJ(r[4], r[6]); DFT2_MJ(r[5], r[7]);
-	DFT2(r[0], r[1]); DFT2_MJ(r[2], r[3]); bf(r[4], r[5], w8, two); bf_mj(r[6], r[7], w8, two);
 }
 
 /* o_pass_radix16_fma, p > 1, in two halves (the 65536-point kernel runs other work between them):
@@ -1077,9 +1058,9 @@ void k1v2_fft_bin(const K1Params p)
 /* ------------------------------------------------------------------------ */
 /* The reference's plan for any N = 8^k * 2 (fft.cl:397-466 is the N = 1024 instance): k radix-8
  * Stockham passes with p = 1, 8, 64, ... and a final radix-2 pass with p = N/2, N/8 work-items
- * of 8 points each.  One work-group of N/8 threads per spectrum (1024 threads for N = 8192),
- * the N-point exchange slab in dynamic LDS (64 KiB at 8192), twiddles and window read from
- * global memory (L2-resident tables; this path is a parity case, not the tuned one).
+ * of 8 points each.  One work-group of N/8 threads per spectrum, the N-point exchange slab, the twiddles and
+ * the window in dynamic LDS.  Instantiated for N = 1024 with 16-bit bin indices (more than 256 bins): a parity
+ * case, not a tuned one (N = 8192 has its own kernel and plan, k1w_fft_bin).
  * Same swizzle phys(e) = e ^ ((e >> 3) & 15): the store patterns of every pass and the
  * lane-contiguous reads stay bank-conflict free for any N (the argument of DESIGN_HISTORY.md only
  * involves address bits 0..6).  Bin indices are 16-bit, 2 spectra per dword. */
@@ -1097,10 +1078,8 @@ void k1big_fft_bin(const K1Params p)
 	const int i = threadIdx.x;
 	const int ntiles = p.total / p.tile;
 	/* the whole twiddle table sits behind the exchange slab in LDS: read from global memory it was 21 B per sample of L2 traffic,
-	 * against 8 B per sample of IQ.  N = 1024: the reference's layout, 7 per item and pass; N = 8192 (the long plan, see bf()):
-	 * 4 per item and pass, the radix-2 pass's, the constant W8 */
-	constexpr bool LONG = (LOG2N != 10);
-	constexpr int TWLEN = LONG ? ((N / 2 - 8) / 7) * 4 + N / 2 + 1 : ((N / 2 - 8) / 7) * 7 + N / 2;	/* (8 + 64 + ... + N/16) * (4 | 7) + N/2 (+ 1) */
+	 * against 8 B per sample of IQ.  The reference's layout, 7 per item and pass, then the radix-2 pass's */
+	constexpr int TWLEN = ((N / 2 - 8) / 7) * 7 + N / 2;	/* (8 + 64 + ... + N/16) * 7 + N/2 */
 	v2f *tws = buf + N;
 	float *wins = reinterpret_cast<float *>(tws + TWLEN);	/* and the window behind it: 160 KiB in all at N = 8192 */
 	for (int k = i; k < TWLEN; k += T)
@@ -1110,7 +1089,6 @@ void k1big_fft_bin(const K1Params p)
 	__syncthreads();
 	const v2f *twg = tws;
 	const v2f s12 = { F_SQRT_1_2, F_SQRT_1_2 };
-	const v2f two = { 2.0f, 2.0f };
 	const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
 	const float vmax_init = -1000.0f / F_HALF_LOG10_2;
 	const float top = (float)(bk.nb - 1);
@@ -1132,16 +1110,12 @@ void k1big_fft_bin(const K1Params p)
 			const float2 *src = p.iq + (size_t)t * p.hop;
 			v2f r[8];
 
-			/* window (fft.cl:415-417); the long plan folds it into the first pass */
+			/* window (fft.cl:415-417) */
 #pragma unroll
 			for (int j = 0; j < 8; j++) {
 				const v2f xv = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(src + i + T * j));
-				if (LONG) {
-					r[j] = xv;
-				} else {
-					const float wv = wins[i + T * j];
-					r[j] = v2f{ xv.x * wv, xv.y * wv };
-				}
+				const float wv = wins[i + T * j];
+				r[j] = v2f{ xv.x * wv, xv.y * wv };
 			}
 
 			/* radix-8 passes p = 1, 8, 64, ... (fft.cl:278-350) */
@@ -1149,26 +1123,13 @@ void k1big_fft_bin(const K1Params p)
 #pragma unroll
 			for (int q8 = 0; q8 < NP8; q8++) {
 				const int k = i & (pp - 1);
-				if (LONG) {
-					if (q8 == 0) {
-						v2f wab[4];
+				if (q8 > 0) {
+					const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
 #pragma unroll
-						for (int j = 0; j < 4; j++)
-							wab[j] = v2f{ wins[i + T * j], wins[i + T * (j + 4)] };
-						pass8_first(r, wab, twg[p.tw_off[NP8]], two);
-					} else {
-						const v2f *tw = twg + p.tw_off[q8 - 1] + k * 4;
-						pass8_fma(r, tw[0], tw[1], tw[2], tw[3], two);
-					}
-				} else {
-					if (q8 > 0) {
-						const v2f *tw = twg + p.tw_off[q8 - 1] + k * 7;
-#pragma unroll
-						for (int j = 1; j < 8; j++)
-							r[j] = c_mul(r[j], tw[j - 1]);
-					}
-					dft8(r, s12);
+					for (int j = 1; j < 8; j++)
+						r[j] = c_mul(r[j], tw[j - 1]);
 				}
+				dft8(r, s12);
 				const int j0 = ((i - k) << 3) + k;
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
@@ -1190,12 +1151,8 @@ void k1big_fft_bin(const K1Params p)
 				const int jb = i + T * c;
 				v2f a = buf[swz(jb)];
 				v2f b = buf[swz(jb + N / 2)];
-				if (LONG) {
-					bf(a, b, twg[p.tw_off[NP8 - 1] + jb], two);		/* o_pass_radix2_fma */
-				} else {
-					b = c_mul(b, twg[p.tw_off[NP8 - 1] + jb]);
-					DFT2(a, b);
-				}
+				b = c_mul(b, twg[p.tw_off[NP8 - 1] + jb]);
+				DFT2(a, b);
 				x[c] = a;		/* column jb */
 				x[c + 4] = b;		/* column jb + N/2 */
 			}

@@ -145,19 +145,19 @@ static void o_pass_radix4(const cf *src, cf *dst, int n, int p)
  * configs C3 / C5 name.  The plans below are THIS BUILD'S OWN CHOICE, restated here operation for
  * operation so that the GPU kernels can be checked bit for bit.  They keep the reference's data flow -- Stockham passes with
  * the indexing of fft.cl:278-350 with 16 in the place of 8: radix 16, p = 1, 16, 256 and then the radix-2 pass of fft.cl:428-458
- * (p = 4096) at N = 8192 (two LDS exchanges and a half instead of the three of 8.8.8.8.2: the GPU kernel's LDS is as busy as its
- * VALUs); p = 1, 16, 256, 4096 at N = 65536 --, twiddle angles from the reference's expression
+ * (p = 4096) at N = 8192 (sixteen points per work-item: the GPU kernel makes two exchanges and a half through its LDS per spectrum);
+ * p = 1, 16, 256, 4096 at N = 65536 --, twiddle angles from the reference's expression
  * -pi k / ((R/2) p) (fft.cl:286-297) through the pinned sin / cos -- and change the ARITHMETIC INSIDE A PASS to what a
  * fused-multiply-add machine does best: the radix-R butterfly is log2(R) radix-2 stages in decimation-in-time form whose
  * twiddles sit ON the butterflies,
  *         a' = a + T b        two fused multiply-adds per component pair:  u = fma(b.yx, (-T.y, T.y), a);  a' = fma(b, T.x, u)
  *         b' = 2 a - a'       one:                                          b' = fma(2, a, -a')
  * instead of "multiply every input by its twiddle (fft.cl:37-46: 2 mul + 1 add/sub per product), then an untwiddled dft8
- * (fft.cl:112-145)".  Per radix-8 pass that is 12 butterflies x 3 packed operations = 36 per 8 points against 49, with 4
- * twiddles per item (w^4, w^2, w, w W8) instead of 7; per radix-16 pass 96 per 16 points against 133, 8 twiddles against 15.
+ * (fft.cl:112-145)".  Per radix-16 pass that is 32 butterflies x 3 packed operations = 96 per 16 points against 133, with 8
+ * twiddles per item (w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3) instead of 15.
  * Every operation is ONE IEEE fused multiply-add (fmaf here, v_pk_fma_f32 there) or one add / multiply: bit-reproducible.
  *
- * Derivation (R = 16; R = 8 drops the first stage): X[m] = sum_j W16^(j m) w^j r[j].  Splitting j = j' + 8 j1:
+ * Derivation (R = 16): X[m] = sum_j W16^(j m) w^j r[j].  Splitting j = j' + 8 j1:
  *   X[m] = sum_{j' < 8} W16^(j' m) w^j' ( r[j'] + (-1)^m0 w^8 r[j' + 8] ),  m0 = m & 1        -> stage A, T = w^8
  * and again with distances 4, 2, 1: the twiddle of a stage is w^(R / 2^s) times the power of W16 its position implies,
  *   B: T = w^4 (-j)^m0      C: T = w^2 W8^m0 (-j)^m1      D: T = w W16^m0 W8^m1 (-j)^m2
@@ -220,41 +220,8 @@ static inline void o_bf_win(cf *a, cf *b, float wa, float wb)
 	b->y = fmaf(-b->y, wb, my);
 }
 
-/* One Stockham radix-8 pass of the long plan (indexing of fft.cl:278-350).  win != NULL: the first pass (p = 1). */
-static void o_pass_radix8_fma(const cf *src, cf *dst, int n, int p, const float *win)
-{
-	const int t = n >> 3;
-	static const int perm[8] = { 0, 4, 2, 6, 1, 5, 3, 7 };
-	const cf w8 = o_tw(1, 4);
-	int i, j;
-
-	for (i = 0; i < t; i++) {
-		cf r[8];
-		const int k = i & (p - 1);
-		const int j0 = ((i - k) << 3) + k;
-
-		for (j = 0; j < 8; j++)
-			r[j] = src[i + j * t];
-
-		if (win) {
-			for (j = 0; j < 4; j++)
-				o_bf_win(&r[j], &r[j + 4], win[i + j * t], win[i + (j + 4) * t]);
-			o_dft2(&r[0], &r[2]); o_dft2(&r[1], &r[3]); o_bf1_mj(&r[4], &r[6]); o_bf1_mj(&r[5], &r[7]);
-			o_dft2(&r[0], &r[1]); o_bf1_mj(&r[2], &r[3]); o_bf(&r[4], &r[5], w8); o_bf_mj(&r[6], &r[7], w8);
-		} else {
-			const cf t4 = o_tw(4 * k, 4 * p), t2 = o_tw(2 * k, 4 * p), t1 = o_tw(k, 4 * p), t1w = o_tw(k + p, 4 * p);
-			for (j = 0; j < 4; j++)
-				o_bf(&r[j], &r[j + 4], t4);
-			o_bf(&r[0], &r[2], t2); o_bf(&r[1], &r[3], t2); o_bf_mj(&r[4], &r[6], t2); o_bf_mj(&r[5], &r[7], t2);
-			o_bf(&r[0], &r[1], t1); o_bf_mj(&r[2], &r[3], t1); o_bf(&r[4], &r[5], t1w); o_bf_mj(&r[6], &r[7], t1w);
-		}
-
-		for (j = 0; j < 8; j++)
-			dst[j0 + j * p] = r[perm[j]];
-	}
-}
-
-/* One Stockham radix-16 pass of the long plan: t = N/16 items of 16 points, angle -pi k / (8 p). */
+/* One Stockham radix-16 pass of the long plans (indexing as fft.cl:278-350 with 16 for 8): t = N/16 items of 16 points, angle
+ * -pi k / (8 p).  win != NULL: the first pass (p = 1). */
 static void o_pass_radix16_fma(const cf *src, cf *dst, int n, int p, const float *win)
 {
 	const int t = n >> 4;
@@ -350,18 +317,15 @@ static void o_fft_one(int log2n, const cf *in, cf *out, const float *win, cf *sc
 	int i, p, done;
 
 	if (log2n == 13 || log2n == 16) {
-		/* this build's plans for the long lengths (see o_pass_radix8_fma): the window rides on the first pass */
-		const int lr = 4;		/* radix-16 passes p = 1, 16, 256 (, 4096); N = 8192 ends with the radix-2 pass p = 4096 */
+		/* this build's plans for the long lengths (see o_pass_radix16_fma): radix-16 passes p = 1, 16, 256 (, 4096), the window on the first;
+		 * N = 8192 ends with the radix-2 pass p = 4096 */
 		const cf *src = in;
 		p = 1;
-		for (done = 0; done + lr <= log2n; done += lr) {
-			if (lr == 4)
-				o_pass_radix16_fma(src, b, n, p, p == 1 ? win : NULL);
-			else
-				o_pass_radix8_fma(src, b, n, p, p == 1 ? win : NULL);
+		for (done = 0; done + 4 <= log2n; done += 4) {
+			o_pass_radix16_fma(src, b, n, p, p == 1 ? win : NULL);
 			tmp = a; a = b; b = tmp;
 			src = a;
-			p <<= lr;
+			p <<= 4;
 		}
 		if (log2n - done == 1) {
 			o_pass_radix2_fma(a, b, n);

@@ -173,6 +173,21 @@ def test_twiddle_table_matches_oracle(amd, oracle_built):
     assert i == n
 
 
+def test_k1w_hand_issued_requests_are_not_touched_before_their_wait():
+    """The 8192-point kernel requests the next spectrum's IQ with inline-assembly buffer loads and waits for them with a hand-written
+    s_waitcnt one iteration later (the compiler's own wait also sat through every index store issued in between).  The compiler does not
+    know those registers are in flight: the compiled code must not read or write them between a request and the wait, in any instantiation
+    (tools/check_k1w_loads.py, on `hipcc -S` of the kernel file)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_k1w_loads.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("untouched until the wait") == 5, r.stdout		# overlap 2, 4, 8, 16 and the general form
+
+
 def test_product_never_touches_the_oracle():
     """The product tree must not import, link or open anything under oracle/ (only tests,
     smoke() and bench's cpu_baseline may)."""

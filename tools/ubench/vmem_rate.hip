@@ -28,6 +28,10 @@ __global__ __launch_bounds__(512) void k(char *buf, int iters, uint32_t *sink)
 			else if (KIND == 5) { u2v t; asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(lane * 8), "s"(base + 512 * (j & 7)) : "memory"); a2 += t; }
 			else if (KIND == 6) { u4v t; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(t) : "v"(lane * 16), "s"(base + 1024 * (j & 7)) : "memory"); a4 += t; }
 			else if (KIND == 7) { uint32_t t; asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(lane * 4), "s"(base + 256 * j) : "memory"); a2.x += t; }
+			else if (KIND == 8) { uint32_t t; asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(lane * 8 + (j & 1) * 4), "s"(base + 512 * (j >> 1)) : "memory"); a2.x += t; }	// 8-byte stride: re / im of an fp32 pair separately
+			else if (KIND == 9) { u2v t; asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(t) : "v"(lane * 8), "s"(base + 512 * (j & 7)) : "memory"); a2 += t; }
+			else if (KIND == 10) { u2v t; asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(t) : "v"(lane * 16), "s"(base + 1024 * (j & 7)) : "memory"); a2 += t; }	// 8 of every 16 bytes
+			else if (KIND == 11) { u2v t = { 0, 0 }; if (lane < 32) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(a4) : "v"(lane * 16), "s"(base + 512 * (j & 7)) : "memory"); a2 += t; }	// half the lanes, 16 B each: the same 512 B
 		}
 		if (KIND >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
@@ -39,14 +43,14 @@ int main()
 {
 	char *d; uint32_t *sink; (void)hipMalloc(&d, 256 * 65536); (void)hipMemset(d, 0, 256 * 65536); (void)hipMalloc(&sink, 64);
 	const char *names[] = {"global_store_short, 2 B per 4", "global_store_short dense", "global_store_dword", "global_store_dwordx2", "global_store_dwordx4",
-	                       "global_load_dwordx2 (+wait per 16)", "global_load_dwordx4 (+wait per 16)", "global_load_dword (+wait per 16)"};
-	for (int kind = 0; kind < 8; kind++) {
+	                       "global_load_dwordx2 (+wait per 16)", "global_load_dwordx4 (+wait per 16)", "global_load_dword (+wait per 16)", "global_load_dword, 8-byte lane stride", "global_load_dwordx2 nt", "global_load_dwordx2, 16-byte lane stride", "global_load_dwordx4, 32 lanes"};
+	for (int kind = 0; kind < 12; kind++) {
 		hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
 		const int iters = 2000;
 		auto launch = [&]() {
 			switch (kind) {
 #define C(K) case K: hipLaunchKernelGGL(k<K>, dim3(256), dim3(512), 0, 0, d, iters, sink); break;
-			C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7)
+			C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11)
 			}
 		};
 		launch(); (void)hipDeviceSynchronize();
