@@ -164,6 +164,56 @@ static __device__ __forceinline__ void bf_mj_s(v2f &a, v2f &b, v2f t, v2f two)
 	asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb) : "v"(a), "s"(two), "v"(pa));
 	a = pa; b = nb;
 }
+/* Eight (CNT) butterflies of one stage, STEP BY STEP (all first operations, all second, all third): written butterfly by butterfly, dependent
+ * inline-assembly statements end up adjacent and the compiler separates each such pair by an s_nop (it assumes a value written by inline
+ * assembly cannot be forwarded): ~50 issue slots per thread and spectrum in the 8192-point kernel.  IA / IB: registers of the a / b inputs,
+ * MJ: bit j set = butterfly j takes -j T (bf_mj). */
+#ifndef BF_STAGEWISE
+#define BF_STAGEWISE 1
+#endif
+template <bool SC, bool TS, int MJ, int I0, int I1, int I2, int I3, int I4, int I5, int I6, int I7, int D, int CNT = 8>
+static __device__ __forceinline__ void bf8(v2f (&r)[16], v2f t0, v2f t1, v2f t2, v2f t3, v2f t4, v2f t5, v2f t6, v2f t7, v2f two)
+{
+	constexpr int ia[8] = { I0, I1, I2, I3, I4, I5, I6, I7 };
+	const v2f t[8] = { t0, t1, t2, t3, t4, t5, t6, t7 };
+	if (BF_STAGEWISE && SC) {		/* (the 65536-point kernel measured 5 % slower in this form: 207 -> 217 registers under its skewed loop) */
+	v2f u[8], pa[8], nb[8];
+#pragma unroll
+	for (int j = 0; j < CNT; j++) {
+		if (MJ & (1 << j)) {
+			if (TS) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u[j]) : "v"(r[ia[j] + D]), "s"(t[j]), "v"(r[ia[j]]));
+			else    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u[j]) : "v"(r[ia[j] + D]), "v"(t[j]), "v"(r[ia[j]]));
+		} else {
+			if (TS) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u[j]) : "v"(r[ia[j] + D]), "s"(t[j]), "v"(r[ia[j]]));
+			else    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u[j]) : "v"(r[ia[j] + D]), "v"(t[j]), "v"(r[ia[j]]));
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < CNT; j++) {
+		if (MJ & (1 << j)) {
+			if (TS) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(pa[j]) : "v"(r[ia[j] + D]), "s"(t[j]), "v"(u[j]));
+			else    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(pa[j]) : "v"(r[ia[j] + D]), "v"(t[j]), "v"(u[j]));
+		} else {
+			if (TS) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa[j]) : "v"(r[ia[j] + D]), "s"(t[j]), "v"(u[j]));
+			else    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa[j]) : "v"(r[ia[j] + D]), "v"(t[j]), "v"(u[j]));
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < CNT; j++) {
+		if (SC) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb[j]) : "v"(r[ia[j]]), "s"(two), "v"(pa[j]));
+		else    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(nb[j]) : "v"(r[ia[j]]), "v"(two), "v"(pa[j]));
+	}
+#pragma unroll
+	for (int j = 0; j < CNT; j++) { r[ia[j]] = pa[j]; r[ia[j] + D] = nb[j]; }
+	} else {
+#pragma unroll
+	for (int j = 0; j < CNT; j++) {
+		if (MJ & (1 << j)) { if (TS) bf_mj_s<SC>(r[ia[j]], r[ia[j] + D], t[j], two); else bf_mj<SC>(r[ia[j]], r[ia[j] + D], t[j], two); }
+		else               { if (TS) bf_s<SC>(r[ia[j]], r[ia[j] + D], t[j], two);    else bf<SC>(r[ia[j]], r[ia[j] + D], t[j], two); }
+	}
+	}
+}
+
 /* o_bf_win, stage A of the first pass: m = a wab.x;  a' = fma(b, wab.y, m);  b' = fma(-b, wab.y, m)   (wab = the two window taps) */
 static __device__ __forceinline__ void bf_win(v2f &a, v2f &b, v2f wab)
 {
@@ -180,35 +230,38 @@ static __device__ __forceinline__ void bf_win(v2f &a, v2f &b, v2f wab)
 template <bool SC = false>
 static __device__ __forceinline__ void pass16_ab(v2f (&r)[16], v2f t8, v2f t4, v2f two)
 {
-#pragma unroll
-	for (int j = 0; j < 8; j++)
-		bf<SC>(r[j], r[j + 8], t8, two);
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		bf<SC>(r[j], r[j + 4], t4, two);
-		bf_mj<SC>(r[8 + j], r[12 + j], t4, two);
-	}
+	bf8<SC, false, 0x00, 0, 1, 2, 3, 4, 5, 6, 7, 8>(r, t8, t8, t8, t8, t8, t8, t8, t8, two);		/* stage A: (j, j + 8) */
+	bf8<SC, false, 0xf0, 0, 1, 2, 3, 8, 9, 10, 11, 4>(r, t4, t4, t4, t4, t4, t4, t4, t4, two);		/* stage B: (j, j + 4); -j on the upper half */
 }
 template <bool SC = false>
 static __device__ __forceinline__ void pass16_cd(v2f (&r)[16], v2f t2, v2f t2w, v2f t1, v2f t1a, v2f t1b, v2f t1c, v2f two)
 {
-#pragma unroll
-	for (int j = 0; j < 2; j++) {
-		bf<SC>(r[j], r[j + 2], t2, two);
-		bf_mj<SC>(r[4 + j], r[6 + j], t2, two);
-		bf<SC>(r[8 + j], r[10 + j], t2w, two);
-		bf_mj<SC>(r[12 + j], r[14 + j], t2w, two);
-	}
-	bf<SC>(r[0], r[1], t1, two);   bf_mj<SC>(r[2], r[3], t1, two);    bf<SC>(r[4], r[5], t1b, two);   bf_mj<SC>(r[6], r[7], t1b, two);
-	bf<SC>(r[8], r[9], t1a, two);  bf_mj<SC>(r[10], r[11], t1a, two); bf<SC>(r[12], r[13], t1c, two); bf_mj<SC>(r[14], r[15], t1c, two);
+	bf8<SC, false, 0xf0, 0, 1, 8, 9, 4, 5, 12, 13, 2>(r, t2, t2, t2w, t2w, t2, t2, t2w, t2w, two);	/* stage C: (j, j + 2) */
+	bf8<SC, false, 0xaa, 0, 2, 4, 6, 8, 10, 12, 14, 1>(r, t1, t1, t1b, t1b, t1a, t1a, t1c, t1c, two);	/* stage D: (j, j + 1) */
 }
 /* ... p = 1: the window on stage A (wab[j] = taps of r[j], r[j + 8]); w16 = W16, w8 = W8, w163 = W16^3 */
 template <bool SC = false>
 static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wab)[8], v2f w16, v2f w8, v2f w163, v2f two)
 {
+	if (BF_STAGEWISE && SC) {
+		/* stage A step by step as well: the products, then the sums, then the differences */
+		v2f m[8], pa[8], nb[8];
 #pragma unroll
-	for (int j = 0; j < 8; j++)
-		bf_win(r[j], r[j + 8], wab[j]);
+		for (int j = 0; j < 8; j++)
+			asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m[j]) : "v"(r[j]), "v"(wab[j]));
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(pa[j]) : "v"(r[j + 8]), "v"(wab[j]), "v"(m[j]));
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(nb[j]) : "v"(r[j + 8]), "v"(wab[j]), "v"(m[j]));
+#pragma unroll
+		for (int j = 0; j < 8; j++) { r[j] = pa[j]; r[j + 8] = nb[j]; }
+	} else {
+#pragma unroll
+		for (int j = 0; j < 8; j++)
+			bf_win(r[j], r[j + 8], wab[j]);
+	}
 #pragma unroll
 	for (int j = 0; j < 4; j++) {
 		DFT2(r[j], r[j + 4]);
@@ -218,11 +271,10 @@ static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wa
 	for (int j = 0; j < 2; j++) {
 		DFT2(r[j], r[j + 2]);
 		DFT2_MJ(r[4 + j], r[6 + j]);
-		bf_s<SC>(r[8 + j], r[10 + j], w8, two);
-		bf_mj_s<SC>(r[12 + j], r[14 + j], w8, two);
 	}
-	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);           bf_s<SC>(r[4], r[5], w8, two);   bf_mj_s<SC>(r[6], r[7], w8, two);
-	bf_s<SC>(r[8], r[9], w16, two); bf_mj_s<SC>(r[10], r[11], w16, two); bf_s<SC>(r[12], r[13], w163, two); bf_mj_s<SC>(r[14], r[15], w163, two);
+	bf8<SC, true, 0x0c, 8, 9, 12, 13, 0, 0, 0, 0, 2, 4>(r, w8, w8, w8, w8, w8, w8, w8, w8, two);	/* stage C, the twiddled half: (8, 10), (9, 11), -j: (12, 14), (13, 15) */
+	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);
+	bf8<SC, true, 0x2a, 4, 6, 8, 10, 12, 14, 0, 0, 1, 6>(r, w8, w8, w16, w16, w163, w163, w8, w8, two);	/* stage D: (4, 5) W8, -j (6, 7) W8, (8, 9) W16, -j (10, 11), (12, 13) W16^3, -j (14, 15) */
 }
 
 /* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
@@ -1606,21 +1658,27 @@ void k1w_fft_bin(const K1Params p)
 				o[c] = K1W_P(2) ? x[c] : slab0[512 * c + (th ^ 256)];
 #endif
 			K1W_STAMP(15);
-			if (hu == 0) {			/* X3[jb] is this item's output m = c, X3[jb + 4096] item th + 256's */
-#pragma unroll
-				for (int c = 0; c < 8; c++) {
-					v2f a = x[R16_PERM(c)], b = o[c];
-					bf<true>(a, b, twr[c], two);
-					xo[c] = a; xo[c + 8] = b;
-				}
-			} else {			/* X3[jb] is item th - 256's output m = 8 + c, X3[jb + 4096] this item's */
-#pragma unroll
-				for (int c = 0; c < 8; c++) {
-					v2f a = o[c], b = x[R16_PERM(8 + c)];
-					bf<true>(a, b, twr[c], two);
-					xo[c] = a; xo[c + 8] = b;
-				}
-			}
+			/* (step by step, like bf8; the two forms differ in where a and b come from) */
+#define K1W_R2(A, B) do { \
+				v2f u[8], pa[8]; \
+				_Pragma("unroll") \
+				for (int c = 0; c < 8; c++) \
+					asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(u[c]) : "v"(B), "v"(twr[c]), "v"(A)); \
+				_Pragma("unroll") \
+				for (int c = 0; c < 8; c++) \
+					asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(pa[c]) : "v"(B), "v"(twr[c]), "v"(u[c])); \
+				_Pragma("unroll") \
+				for (int c = 0; c < 8; c++) \
+					asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(xo[c + 8]) : "v"(A), "s"(two), "v"(pa[c])); \
+				_Pragma("unroll") \
+				for (int c = 0; c < 8; c++) \
+					xo[c] = pa[c]; \
+			} while (0)
+			if (hu == 0)			/* X3[jb] is this item's output m = c, X3[jb + 4096] item th + 256's */
+				K1W_R2(x[R16_PERM(c)], o[c]);
+			else				/* X3[jb] is item th - 256's output m = 8 + c, X3[jb + 4096] this item's */
+				K1W_R2(o[c], x[R16_PERM(8 + c)]);
+#undef K1W_R2
 		}
 
 		if (p.fft_out) {		/* (tests) */
