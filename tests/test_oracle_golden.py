@@ -98,8 +98,8 @@ def test_fft1024_is_a_dft(oracle_built):
 @pytest.mark.parametrize("log2n", [13, 16])
 def test_long_fft_plans_are_dfts(oracle_built, log2n):
     """No reference behaviour exists beyond N = 1024: the plans are the oracle's -- the reference's Stockham data flow (8192: radix
-    8.8.8.8.2, fft.cl:278-350,397-466 generalised; 65536: radix 16.16.16.16) with the arithmetic inside a pass restated as
-    fused-multiply-add butterflies that carry their twiddles (o_pass_radix8_fma / o_pass_radix16_fma / o_pass_radix2_fma, round 5).
+    16.16.16.2, fft.cl:278-350,397-466 generalised; 65536: radix 16.16.16.16) with the arithmetic inside a pass restated as
+    fused-multiply-add butterflies that carry their twiddles (o_pass_radix16_fma / o_pass_radix2_fma, round 5).
     Whatever the plan, it must BE a forward, unnormalised, natural-order DFT -- as accurate against numpy's fp64 FFT as the
     reference's own 1024-point kernel is."""
     n = 1 << log2n
