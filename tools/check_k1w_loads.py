@@ -2,7 +2,7 @@
 """Build-time check of the 8192-point kernel's hand-issued IQ requests (gr-fosphor_amd/csrc/fosphor_kernels.hip, k1w_fft_bin).
 
 The kernel requests the next spectrum's IQ with `buffer_load_dwordx2` written as inline assembly and waits for it with a hand-written
-`s_waitcnt vmcnt(16)` at the top of the next iteration, so the compiler does not know that the destination registers are in flight.  That is
+`s_waitcnt vmcnt(16)` at the top of the next iteration, so the compiler does not know that the destination registers are in flight (8-byte requests per row, or 16-byte requests per pair of rows).  That is
 only correct if NOTHING reads or writes those registers between a request and the wait: a register-allocator copy in between would copy
 stale data.  This script compiles the kernels to assembly and checks exactly that, for every instantiation:
 
@@ -60,12 +60,12 @@ def check(path):
         tail = max(i for i, _ in back)
         header = min(h for _, h in back)
         label = body[header].split(":")[0]
-        loads = [i for i in range(w, tail) if "buffer_load_dwordx2" in body[i]]
+        loads = [i for i in range(w, tail) if re.search(r"buffer_load_dwordx[24] ", body[i])]
         if not loads:
             raise SystemExit("%s: no IQ request inside the loop" % name)
         dests, bad = set(), []
         for ld in loads:		# a register is in flight from ITS request to the wait
-            m = re.search(r"buffer_load_dwordx2 v\[(\d+):(\d+)\]", body[ld])
+            m = re.search(r"buffer_load_dwordx[24] v\[(\d+):(\d+)\]", body[ld])
             d = set(range(int(m.group(1)), int(m.group(2)) + 1))
             dests |= d
             for i in list(range(ld + 1, tail + 1)) + list(range(header, w)):
