@@ -61,6 +61,23 @@ static __device__ __forceinline__ v2f c_mul(v2f a, v2f w)
 	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));			/* (t1.x - t2.x, t1.y + t2.y) */
 	return r;
 }
+/* N complex products step by step (all first products, all second, all sums; pinned order): written one after the other, the dependent
+ * statements of a product end up adjacent and the compiler puts an s_nop between them (it assumes a value written by inline assembly
+ * cannot be forwarded) -- 28 issue slots per spectrum in the 1024-point kernel.  out[j] = in[j] * w[j], the same three operations. */
+template <int N>
+static __device__ __forceinline__ void c_mul_n(v2f (&out)[N], const v2f (&in)[N], const v2f (&w)[N])
+{
+	v2f t1[N], t2[N];
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t1[j]) : "v"(in[j]), "v"(w[j]));
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t2[j]) : "v"(in[j]), "v"(w[j]));
+#pragma unroll
+	for (int j = 0; j < N; j++)
+		asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(out[j]) : "v"(t1[j]), "v"(t2[j]));
+}
 
 /* a + mul_p1q2(b) and a - mul_p1q2(b), mul_p1q2(b) = (b.y, -b.x)  (fft.cl:77, used by dft8) */
 static __device__ __forceinline__ v2f add_mj(v2f a, v2f b)
@@ -683,10 +700,17 @@ void k1_fft_bin(const K1Params p)
 #pragma unroll
 			for (int v = 0; v < 2; v++) {
 				v2f r[8];
-				r[0] = x[v];
+				{
+					v2f in7[7], out7[7];
 #pragma unroll
-				for (int j = 1; j < 8; j++)
-					r[j] = c_mul(x[v + 2 * j], tw2[j - 1]);
+					for (int j = 1; j < 8; j++)
+						in7[j - 1] = x[v + 2 * j];
+					c_mul_n<7>(out7, in7, tw2);
+					r[0] = x[v];
+#pragma unroll
+					for (int j = 1; j < 8; j++)
+						r[j] = out7[j - 1];
+				}
 				dft8(r, s12);
 #pragma unroll
 				for (int jj = 0; jj < 8; jj++)
@@ -709,10 +733,17 @@ void k1_fft_bin(const K1Params p)
 #pragma unroll
 				for (int v = 0; v < 2; v++) {
 					v2f r[8];
-					r[0] = x[v];
+					{
+						v2f in7[7], out7[7];
 #pragma unroll
-					for (int j = 1; j < 8; j++)
-						r[j] = c_mul(x[v + 2 * j], tw3[j - 1]);
+						for (int j = 1; j < 8; j++)
+							in7[j - 1] = x[v + 2 * j];
+						c_mul_n<7>(out7, in7, tw3);
+						r[0] = x[v];
+#pragma unroll
+						for (int j = 1; j < 8; j++)
+							r[j] = out7[j - 1];
+					}
 					dft8(r, s12);
 #pragma unroll
 					for (int jj = 0; jj < 8; jj++)
@@ -727,13 +758,19 @@ void k1_fft_bin(const K1Params p)
 			/* ---- pass 4: radix 2, p = 512 (fft.cl:428-458) ------------------
 			 * butterfly on elements (j, j + 512), j = lane + 64c, twiddle k = j.
 			 * Results: X[j] -> x[c], X[j + 512] -> x[c + 8], i.e. column lane + 64m. */
+			{
+				v2f in8[8], w8[8], out8[8];
 #pragma unroll
-			for (int c = 0; c < 8; c++) {
-				v2f a = x[c];
-				v2f b = c_mul(x[c + 8], tw4_tab[lane + 64 * c]);	/* k = lane + 64c */
-				DFT2(a, b);
-				x[c] = a;
-				x[c + 8] = b;
+				for (int c = 0; c < 8; c++) { in8[c] = x[c + 8]; w8[c] = tw4_tab[lane + 64 * c]; }	/* k = lane + 64c */
+				c_mul_n<8>(out8, in8, w8);
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					v2f a = x[c];
+					v2f b = out8[c];
+					DFT2(a, b);
+					x[c] = a;
+					x[c + 8] = b;
+				}
 			}
 
 			K1_STAMP(4);		/* pass 4 */
