@@ -188,12 +188,12 @@ static __device__ __forceinline__ void bf_mj_s(v2f &a, v2f &b, v2f t, v2f two)
 #ifndef BF_STAGEWISE
 #define BF_STAGEWISE 1
 #endif
-template <bool SC, bool TS, int MJ, int I0, int I1, int I2, int I3, int I4, int I5, int I6, int I7, int D, int CNT = 8>
+template <bool SC, bool TS, int MJ, int I0, int I1, int I2, int I3, int I4, int I5, int I6, int I7, int D, int CNT = 8, bool SW = SC>
 static __device__ __forceinline__ void bf8(v2f (&r)[16], v2f t0, v2f t1, v2f t2, v2f t3, v2f t4, v2f t5, v2f t6, v2f t7, v2f two)
 {
 	constexpr int ia[8] = { I0, I1, I2, I3, I4, I5, I6, I7 };
 	const v2f t[8] = { t0, t1, t2, t3, t4, t5, t6, t7 };
-	if (BF_STAGEWISE && SC) {		/* (the 65536-point kernel measured 5 % slower in this form: 207 -> 217 registers under its skewed loop) */
+	if (BF_STAGEWISE && SW) {		/* (SW: the 65536-point kernel measured 5 % slower in this form: 207 -> 217 registers under its skewed loop) */
 	v2f u[8], pa[8], nb[8];
 #pragma unroll
 	for (int j = 0; j < CNT; j++) {
@@ -244,23 +244,23 @@ static __device__ __forceinline__ void bf_win(v2f &a, v2f &b, v2f wab)
 /* o_pass_radix16_fma, p > 1, in two halves (the 65536-point kernel runs other work between them):
  * stages A, B: t8 = w^8, t4 = w^4;  stages C, D: t2 = w^2, t2w = w^2 W8, t1 = w, t1a = w W16, t1b = w W8, t1c = w W16^3.
  * X[m] is left in r[bitrev4(m)] (R16_PERM). */
-template <bool SC = false>
+template <bool SC = false, bool SW = SC>
 static __device__ __forceinline__ void pass16_ab(v2f (&r)[16], v2f t8, v2f t4, v2f two)
 {
-	bf8<SC, false, 0x00, 0, 1, 2, 3, 4, 5, 6, 7, 8>(r, t8, t8, t8, t8, t8, t8, t8, t8, two);		/* stage A: (j, j + 8) */
-	bf8<SC, false, 0xf0, 0, 1, 2, 3, 8, 9, 10, 11, 4>(r, t4, t4, t4, t4, t4, t4, t4, t4, two);		/* stage B: (j, j + 4); -j on the upper half */
+	bf8<SC, false, 0x00, 0, 1, 2, 3, 4, 5, 6, 7, 8, 8, SW>(r, t8, t8, t8, t8, t8, t8, t8, t8, two);		/* stage A: (j, j + 8) */
+	bf8<SC, false, 0xf0, 0, 1, 2, 3, 8, 9, 10, 11, 4, 8, SW>(r, t4, t4, t4, t4, t4, t4, t4, t4, two);		/* stage B: (j, j + 4); -j on the upper half */
 }
-template <bool SC = false>
+template <bool SC = false, bool SW = SC>
 static __device__ __forceinline__ void pass16_cd(v2f (&r)[16], v2f t2, v2f t2w, v2f t1, v2f t1a, v2f t1b, v2f t1c, v2f two)
 {
-	bf8<SC, false, 0xf0, 0, 1, 8, 9, 4, 5, 12, 13, 2>(r, t2, t2, t2w, t2w, t2, t2, t2w, t2w, two);	/* stage C: (j, j + 2) */
-	bf8<SC, false, 0xaa, 0, 2, 4, 6, 8, 10, 12, 14, 1>(r, t1, t1, t1b, t1b, t1a, t1a, t1c, t1c, two);	/* stage D: (j, j + 1) */
+	bf8<SC, false, 0xf0, 0, 1, 8, 9, 4, 5, 12, 13, 2, 8, SW>(r, t2, t2, t2w, t2w, t2, t2, t2w, t2w, two);	/* stage C: (j, j + 2) */
+	bf8<SC, false, 0xaa, 0, 2, 4, 6, 8, 10, 12, 14, 1, 8, SW>(r, t1, t1, t1b, t1b, t1a, t1a, t1c, t1c, two);	/* stage D: (j, j + 1) */
 }
 /* ... p = 1: the window on stage A (wab[j] = taps of r[j], r[j + 8]); w16 = W16, w8 = W8, w163 = W16^3 */
-template <bool SC = false>
+template <bool SC = false, bool SW = SC>
 static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wab)[8], v2f w16, v2f w8, v2f w163, v2f two)
 {
-	if (BF_STAGEWISE && SC) {
+	if (BF_STAGEWISE && SW) {
 		/* stage A step by step as well: the products, then the sums, then the differences */
 		v2f m[8], pa[8], nb[8];
 #pragma unroll
@@ -289,9 +289,9 @@ static __device__ __forceinline__ void pass16_first(v2f (&r)[16], const v2f (&wa
 		DFT2(r[j], r[j + 2]);
 		DFT2_MJ(r[4 + j], r[6 + j]);
 	}
-	bf8<SC, true, 0x0c, 8, 9, 12, 13, 0, 0, 0, 0, 2, 4>(r, w8, w8, w8, w8, w8, w8, w8, w8, two);	/* stage C, the twiddled half: (8, 10), (9, 11), -j: (12, 14), (13, 15) */
+	bf8<SC, true, 0x0c, 8, 9, 12, 13, 0, 0, 0, 0, 2, 4, SW>(r, w8, w8, w8, w8, w8, w8, w8, w8, two);	/* stage C, the twiddled half: (8, 10), (9, 11), -j: (12, 14), (13, 15) */
 	DFT2(r[0], r[1]);          DFT2_MJ(r[2], r[3]);
-	bf8<SC, true, 0x2a, 4, 6, 8, 10, 12, 14, 0, 0, 1, 6>(r, w8, w8, w16, w16, w163, w163, w8, w8, two);	/* stage D: (4, 5) W8, -j (6, 7) W8, (8, 9) W16, -j (10, 11), (12, 13) W16^3, -j (14, 15) */
+	bf8<SC, true, 0x2a, 4, 6, 8, 10, 12, 14, 0, 0, 1, 6, SW>(r, w8, w8, w16, w16, w163, w163, w8, w8, two);	/* stage D: (4, 5) W8, -j (6, 7) W8, (8, 9) W16, -j (10, 11), (12, 13) W16^3, -j (14, 15) */
 }
 
 /* x * w with w broadcast from the low / high half of a pair (fft.cl:415-417) */
@@ -1798,6 +1798,9 @@ void k1w_fft_bin(const K1Params p)
 #ifndef K1H_LOAD_ORDER
 #define K1H_LOAD_ORDER 1
 #endif
+#ifndef K1H_SC
+#define K1H_SC false		/* (A/B builds) true: (2, 2) and the uniform twiddles of the first pass in scalar registers, like the 8192-point kernel */
+#endif
 #define K1H_PAIR(i) (K1H_LOAD_ORDER ? ((((i) & 1) << 3) | ((i) >> 1)) : (i))
 #ifndef K1H_SPLIT
 #define K1H_SPLIT 1			/* where the second pass of the NEXT spectrum's stage A runs (A/B builds): 0 stages A, B behind the arrival at the cluster
@@ -2020,13 +2023,13 @@ void k1h_fused(const K1Params p)
 		}
 		/* first pass (p = 1), the window of fft.cl:415-417 on its stage-A butterflies */
 		if constexpr (HALF) {
-			pass16_first(ra, wab, w16c, w8c, w163c, two);
+			pass16_first<K1H_SC, false>(ra, wab, w16c, w8c, w163c, two);
 		} else {
 			v2f wl[8];
 #pragma unroll
 			for (int j = 0; j < 8; j++)
 				wl[j] = v2f{ p.win[qa + 256 * (ia + 16 * j)], p.win[qa + 256 * (ia + 16 * (j + 8))] };
-			pass16_first(ra, wl, w16c, w8c, w163c, two);
+			pass16_first<K1H_SC, false>(ra, wl, w16c, w8c, w163c, two);
 		}
 	};
 	/* ... and the 16 x 16 transpose inside the wave that follows it */
@@ -2058,8 +2061,8 @@ void k1h_fused(const K1Params p)
 	const v2f *twa_r = twa_t + ia * kTwRow;
 	const v2f *tw3_r = tw3_t + kkl * kTwRow;
 #endif
-	auto stage_a2_ab = [&]() { pass16_ab(ra, twa_r[0], twa_r[1], two); };
-	auto stage_a2_cd = [&]() { pass16_cd(ra, twa_r[2], twa_r[3], twa_r[4], twa_r[5], twa_r[6], twa_r[7], two); };
+	auto stage_a2_ab = [&]() { pass16_ab<K1H_SC, false>(ra, twa_r[0], twa_r[1], two); };
+	auto stage_a2_cd = [&]() { pass16_cd<K1H_SC, false>(ra, twa_r[2], twa_r[3], twa_r[4], twa_r[5], twa_r[6], twa_r[7], two); };
 	auto stage_a2 = [&]() { stage_a2_ab(); stage_a2_cd(); };
 
 #if K1H_TIMING
@@ -2185,7 +2188,7 @@ void k1h_fused(const K1Params p)
 			}
 		}
 		K1H_STAMP(7);		/* loads of the intermediate issued + second pass of the next spectrum */
-		pass16_ab(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
+		pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
 #if K1H_TIMING
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -2195,7 +2198,7 @@ void k1h_fused(const K1Params p)
 		 * loads return in order, and these come from HBM */
 		if (u + 3 < p.tile)
 			fetch_iq(t + 3, (u + 1) & 1);
-		pass16_cd(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
+		pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
 #pragma unroll
 		for (int jj = 0; jj < 16; jj++)
 			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
@@ -2208,8 +2211,8 @@ void k1h_fused(const K1Params p)
 #pragma unroll
 		for (int jo = 0; jo < 16; jo++)
 			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
-		pass16_ab(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
-		pass16_cd(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
+		pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
+		pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
 
 		K1H_STAMP(11);		/* exchange loads + fourth pass */
 		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
