@@ -2457,6 +2457,14 @@ hipError_t launch_bin_hook(const float2 *fft, uint8_t *bin, float *pwr, int n,
  * 72 us). */
 /* NW waves per work-group: 4 where the kernel has to fit beside K1 (8-bit indices, N = 1024); 16 for the
  * 16-bit-index geometries, whose grids are small (N/64 x chunks) and whose rows are latency-bound */
+/* K2_TIMING (probe builds with -DFOSPHOR_AMD_PROBES -DK2_TIMING, tools/k2_phase_timing.py): s_memtime stamps per phase of the count kernel, summed
+ * over the work-groups' first waves into g_k2_time[] (read through fosphor_amd_debug_k2_timing) */
+#if defined(FOSPHOR_AMD_PROBES) && defined(K2_TIMING)
+__device__ unsigned long long g_k2_time[16];
+#define K2_STAMP(i) do { if (tid == 0) { const long long _n = __builtin_readcyclecounter(); atomicAdd(&g_k2_time[i], (unsigned long long)(_n - k2prev)); k2prev = _n; } } while (0)
+#else
+#define K2_STAMP(i) do { } while (0)
+#endif
 #ifndef K2_DBG
 #define K2_DBG 0		/* measurement only (wrong counts): 1 no LDS atomics, 2 plain LDS stores instead (profiles/r04_ceiling.md) */
 #endif
@@ -2490,6 +2498,10 @@ void k2_count(const K2Params p)
 	const int nb   = p.n_bins;
 	const int hcol = lane & 31;
 	const uint32_t inc = (lane & 32) ? 0x10000u : 1u;
+#if defined(FOSPHOR_AMD_PROBES) && defined(K2_TIMING)
+	long long k2prev = __builtin_readcyclecounter();
+	if (tid == 0) atomicAdd(&g_k2_time[15], 1ull);		/* work-groups */
+#endif
 
 	__shared__ uint32_t rowbits[16];		/* n_bins <= 512 */
 	{
@@ -2500,7 +2512,9 @@ void k2_count(const K2Params p)
 	}
 	if (tid < 16)
 		rowbits[tid] = 0;
+	K2_STAMP(0);		/* zeroing issued */
 	__syncthreads();
+	K2_STAMP(1);		/* barrier */
 
 	/* bins: one dword = 4 consecutive spectra of one column (8-bit indices), or 2 (16-bit
 	 * indices, n_bins > 256 or N > 1024); a wave reads 256 contiguous bytes per row */
@@ -2599,6 +2613,7 @@ void k2_count(const K2Params p)
 		}
 	}
 
+	K2_STAMP(2);		/* counting loop (wave 0) */
 	/* live sum: sum_t pwr_t (1-a)^(B-1-t) from the tile partials, which hold
 	 * sum_{t in tile} pwr_t (1-a)^(t_last - t) (display.cl:149-150) */
 	{
@@ -2616,7 +2631,9 @@ void k2_count(const K2Params p)
 		red_s[wv][lane] = s;
 		red_m[wv][lane] = m;
 	}
+	K2_STAMP(3);		/* live-sum partials */
 	__syncthreads();
+	K2_STAMP(4);		/* barrier: the slowest wave's counting */
 
 	if (tid < 64) {
 		float s = 0.0f, m = -1000.0f;
@@ -2646,9 +2663,11 @@ void k2_count(const K2Params p)
 						atomicOr(&rowbits[i >> 10], 1u << ((i >> 5) & 31));
 				}
 			}
+			K2_STAMP(5);		/* sparse hand-off */
 			__syncthreads();
 			if (tid < p.mask_words)
 				p.rowmask[((size_t)blockIdx.x * p.mask_words + tid) * p.mask_stride + c] = rowbits[tid];
+			K2_STAMP(6);
 			return;
 		}
 		{
@@ -2676,6 +2695,17 @@ void k2_count(const K2Params p)
 		}
 	}
 }
+
+#if defined(FOSPHOR_AMD_PROBES) && defined(K2_TIMING)
+extern "C" int fosphor_amd_debug_k2_timing(unsigned long long *out, int reset)
+{
+	unsigned long long z[16] = {};
+	if (hipDeviceSynchronize() != hipSuccess) return -1;
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k2_time), sizeof(z)) != hipSuccess) return -2;
+	if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_k2_time), z, sizeof(z)) != hipSuccess) return -3;
+	return 0;
+}
+#endif
 
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
