@@ -2710,6 +2710,9 @@ extern "C" int fosphor_amd_debug_k2_timing(unsigned long long *out, int reset)
 hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 {
 	const size_t lds = (size_t)p.n_bins * 32 * sizeof(uint32_t);
+#ifndef K2_IF8
+#define K2_IF8 8		/* ... 8-bit indices, chunks of at most 1024 spectra (A/B builds) */
+#endif
 #ifndef K2_IF16
 #define K2_IF16 4		/* index loads in flight per thread, 16-bit / 9-bit index geometries (A/B builds) */
 #endif
@@ -2718,7 +2721,7 @@ hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 	else if (p.chunk > 1024)
 		hipLaunchKernelGGL((k2_count<4, 4>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	else
-		hipLaunchKernelGGL((k2_count<4, 8>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
+		hipLaunchKernelGGL((k2_count<4, K2_IF8>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);
 	return hipGetLastError();
 }
 
