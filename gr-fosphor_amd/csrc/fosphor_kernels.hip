@@ -1811,6 +1811,29 @@ void k1w_fft_bin(const K1Params p)
 #ifndef K1H_TIMING
 #define K1H_TIMING 0
 #endif
+/* K1H_SPOLL=1 (round 6): the "has every member read the intermediate" question is asked by EVERY wave for itself, through the SCALAR data
+ * path (s_dcache_inv + s_load_dword: its answer does not queue behind the wave's vector stores -- another counter, another path), right before the
+ * wave's stores of the next spectrum: by then the answer has long been yes.  Before, the last wave asked ahead of its epilogue (a vector
+ * load behind the epilogue's stores would have waited for them), saw the spread between the cluster's members (~1 900 cycles per spectrum,
+ * K1H_TIMING builds) and everybody else sat at a work-group barrier for the answer.  That barrier goes with it: nothing else needs it
+ * (the exchange array's readers are separated from its next writers by the barrier behind the stores). */
+#ifndef K1H_SPOLL
+#define K1H_SPOLL 1
+#endif
+#ifndef K1H_SCHED
+#define K1H_SCHED 1		/* 1: the in-line hand-over of rounds 4-5; 2: hand-overs half an iteration late (round 6: built, parity-green, 25 % slower) */
+#endif
+#ifndef K1H_NBUF
+#define K1H_NBUF 1		/* intermediates per cluster (K1H_SCHED == 2): 2 = the slot of cluster gc + 4 as a second buffer (4 MiB per XCD: all of its L2) */
+#endif
+static __device__ __forceinline__ uint32_t sload_fresh(const uint32_t *p)
+{
+	uint32_t v;
+	/* (NOT `s_load_dword ... glc`: tools/ubench/poll_latency.hip measured 16 200 ticks per look for it on gfx950, against 217 for an
+	 * invalidate of the scalar cache followed by a plain scalar load and 253 for a vector load with sc1) */
+	asm volatile("s_dcache_inv\n\ts_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+	return v;
+}
 #if K1H_TIMING
 #define K1H_STAMP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
 		const long long _now = __builtin_readcyclecounter(); hacc[i] += _now - hprev; hprev = _now; } while (0)
@@ -1819,19 +1842,29 @@ void k1w_fft_bin(const K1Params p)
 #endif
 
 constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [residue 4][jj 16][a 16], rows padded to 17 */
-constexpr int kXbLen  = 32 * 257;		/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
-constexpr int kXLen   = 8 * kXaWave > kXbLen ? 8 * kXaWave : kXbLen;	/* the two exchanges share one region (a barrier separates their uses) */
-constexpr int kInLen  = 256 * 32;		/* staged fp16 input of one spectrum: [row m 256][residue 32] dwords, 16-byte pieces permuted inside a row */
 constexpr int kThrMax  = 520;			/* exact-bin thresholds kept in LDS (n_bins + 1 <= 513 doubles) */
 constexpr int kTwRow = 9;			/* LDS twiddle tables: 8 twiddles per row, rows padded to 9 entries (72 B: 16 / 32 rows fall into different banks) */
-constexpr size_t kK1hLds = ((size_t)kXLen + 16 * kTwRow + 32 * kTwRow) * sizeof(float2) + (size_t)2 * kInLen * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
-						/* (exchange, two twiddle tables, staged input + window taps in the same layout, thresholds) */
+/* The work-group's size decides the cluster's: a work-group of NWV waves takes 4 NWV residues (stage A) / offsets (stage B) of a spectrum,
+ * so 64 / NWV work-groups make a cluster.  NWV = 8: one work-group per CU, clusters of 8.  NWV = 4 (round 6): TWO work-groups per CU --
+ * members of different clusters, each with its own barriers -- so the CU's two halves are at different points of the loop and one's
+ * arithmetic runs beside the other's LDS / memory phases; clusters of 16. */
+template <int NWV> struct K1hGeom {
+	static constexpr int kMem   = 64 / NWV;		/* members of a cluster */
+	static constexpr int kRpm   = 4 * NWV;		/* residues = offsets per member */
+	static constexpr int kXbLen = kRpm * 257;	/* stage-B exchange: [offset][jj3 16][a3 16], offsets padded to 257 */
+	static constexpr int kXLen  = NWV * kXaWave > kXbLen ? NWV * kXaWave : kXbLen;	/* the two exchanges share one region (a barrier separates their uses) */
+	static constexpr int kInLen = 256 * kRpm;	/* staged fp16 input of one spectrum: [row m 256][residue] dwords, 16-byte pieces permuted inside a row */
+	static constexpr size_t kLds = ((size_t)kXLen + 16 * kTwRow + kRpm * kTwRow) * sizeof(float2) + (size_t)2 * kInLen * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
+						/* (exchange, two twiddle tables, staged input, thresholds) */
+};
 
-template <bool HALF, bool WRITE_FFT>
-__global__ __launch_bounds__(512, 2)
+template <bool HALF, bool WRITE_FFT, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2)
 void k1h_fused(const K1Params p)
 {
 	constexpr int N = 65536;
+	typedef K1hGeom<NWV> G;
+	constexpr int NT = 64 * NWV, kMem = G::kMem, kRpm = G::kRpm, kXLen = G::kXLen, kInLen = G::kInLen;
 	/* Every wait on another work-group is bounded (a poll is ~1 us: seconds, far beyond any legitimate wait): a protocol failure
 	 * ends the kernel with an error word the host turns into -EIO, it does not hang the GPU. */
 	constexpr uint32_t kSpinLimit = 4u << 20;
@@ -1840,7 +1873,7 @@ void k1h_fused(const K1Params p)
 	v2f *xb = xa_all;						/* ... stage B: the work-group's exchange array, in the same memory */
 	v2f *twa_t = xa_all + kXLen;					/* pass-2 twiddles [k2 16][8 of kTwRow] */
 	v2f *tw3_t = twa_t + 16 * kTwRow;				/* pass-3 twiddles of this member's 32 offsets [32][8 of kTwRow] */
-	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + 32 * kTwRow);	/* fp16 IQ of the next two spectra (two buffers of kInLen dwords) */
+	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + kRpm * kTwRow);	/* fp16 IQ of the next two spectra (two buffers of kInLen dwords) */
 	/* the exact-bin thresholds: the rare path that consults them must not wait for the loads and stores in flight (LDS reads have
 	 * their own counter) */
 	typedef const __attribute__((address_space(3))) double *lds_cdp;
@@ -1866,9 +1899,9 @@ void k1h_fused(const K1Params p)
 		if (tk < 64) {
 			/* the cluster's state: 0 forming, 1 complete (set by the holder of its 8th ticket: all 8 are resident),
 			 * 2 abandoned (set by a member that saw the tiles run out first) -- one compare-and-swap decides */
-			uint32_t *state = p.sync + ((int)xcc * 8 + (int)(tk >> 3)) * 64 + 24;
+			uint32_t *state = p.sync + ((int)xcc * 8 + (int)(tk / kMem)) * 64 + 24;
 			uint32_t st = 0;
-			if ((tk & 7) == 7) {
+			if ((tk % kMem) == kMem - 1) {
 				__hip_atomic_compare_exchange_strong(state, &st, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			} else {
@@ -1897,7 +1930,7 @@ void k1h_fused(const K1Params p)
 			sh_ticket = (int)__hip_atomic_fetch_add(p.sync + 63 * 64 + 60, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		__syncthreads();
 		if (sh_ticket == (int)gridDim.x - 1)
-			for (int e = tid; e < 64 * 64; e += 512)
+			for (int e = tid; e < 64 * 64; e += NT)
 				__hip_atomic_store(p.sync + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
 	if (sh_ticket < 0) {
@@ -1907,8 +1940,8 @@ void k1h_fused(const K1Params p)
 	/* (everything that is the same for the whole work-group is forced into SGPRs: addresses are then a scalar base plus ONE
 	 * 32-bit per-lane offset -- global_load / global_store ... s[base:base+1] -- instead of a 64-bit vector add per access) */
 	const int ticket = __builtin_amdgcn_readfirstlane(sh_ticket);
-	const int member = ticket & 7;
-	const int gc = (int)xcc * 8 + (ticket >> 3);			/* cluster: up to 8 per XCD */
+	const int member = ticket % kMem;
+	const int gc = (int)xcc * 8 + ticket / kMem;			/* cluster: up to 8 per XCD */
 	uint32_t *c_a = p.sync + gc * 64;				/* stage A done */
 	uint32_t *c_t = p.sync + gc * 64 + 16;				/* (round << 20) | tile, published by member 0 */
 	uint32_t *c_b = p.sync + gc * 64 + 32;				/* stage B has read the intermediate */
@@ -1930,14 +1963,17 @@ void k1h_fused(const K1Params p)
 	 *          index kk); after the exchange the same thread is pass-4 item jj3 = tid >> 5 (twiddle index kk + 256 jj3)
 	 *          and owns columns kk + 256 jj3 + 4096 jj4 */
 	const int sa = lane >> 4, ia = lane & 15;
-	const int qa = 32 * member + 4 * wv + sa;
-	const int kkl = tid & 31, ib = tid >> 5;
-	const int kk = 32 * member + kkl;
+	const int qa = kRpm * member + 4 * wv + sa;
+	const int kkl = tid % kRpm, ib = tid / kRpm;
+	const int kk = kRpm * member + kkl;
 	const int col0 = kk + 256 * ib;
 	const unsigned ucol0 = (unsigned)col0;				/* the one per-lane offset of every output access */
-	const unsigned wst0 = 8u * (unsigned)(qa * 32 + (ia ^ ((qa & 1) << 4)));		/* stage-A stores of even / odd jj (byte offsets) */
+	/* the intermediate is [offset / kRpm][residue][offset % kRpm].  32 offsets per block: see the stores below; 16: a row is one 128-byte run */
+	const unsigned wst0 = kRpm == 32 ? 8u * (unsigned)(qa * 32 + (ia ^ ((qa & 1) << 4)))		/* stage-A stores of even / odd jj (byte offsets) */
+	                                 : 8u * (unsigned)(qa * 16 + ia);
 	const unsigned wst1 = wst0 ^ 128u;
-	const unsigned wld = 8u * (unsigned)(ib * 32 + (kkl ^ ((ib & 1) << 4)));		/* stage-B loads */
+	const unsigned wld = kRpm == 32 ? 8u * (unsigned)(ib * 32 + (kkl ^ ((ib & 1) << 4)))		/* stage-B loads */
+	                                : 8u * (unsigned)(ib * 16 + kkl);
 	const __amdgpu_buffer_rsrc_t rs_wf = make_rsrc(p.wf), rs_part = make_rsrc(p.partial);
 
 	const v2f w16c = twg[p.tw_off[0]], w8c = twg[p.tw_off[0] + 1], w163c = twg[p.tw_off[0] + 2];	/* W16, W8, W16^3: the first pass */
@@ -1951,12 +1987,12 @@ void k1h_fused(const K1Params p)
 #pragma unroll
 	for (int j = 0; j < 8; j++)
 		tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 8 + j];
-	for (int e = tid; e <= p.n_bins && e < kThrMax; e += 512)
+	for (int e = tid; e <= p.n_bins && e < kThrMax; e += NT)
 		thr_g[e] = p.thr[e];
-	for (int e = tid; e < 16 * 8; e += 512)
+	for (int e = tid; e < 16 * 8; e += NT)
 		twa_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[1] + e];
-	for (int e = tid; e < 32 * 8; e += 512)
-		tw3_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[2] + (32 * member) * 8 + e];
+	for (int e = tid; e < kRpm * 8; e += NT)
+		tw3_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[2] + (kRpm * member) * 8 + e];
 	__syncthreads();
 
 	v2f *xa = xa_all + wv * kXaWave;
@@ -1965,6 +2001,17 @@ void k1h_fused(const K1Params p)
 	const int eb_w = kkl * 257 + ib;		/* + 16 jj3: pass-3 outputs [offset][jj3][a3] */
 	const int eb_r = kkl * 257 + ib * 16;		/* + j4    : pass-4 inputs of item jj3 = ib */
 
+#ifndef K1H_PRIO
+#define K1H_PRIO 1
+#endif
+#if K1H_PRIO		/* (A/B builds) issue priority by wave: 1 = the upper half of the work-group above the lower, 2 = the last wave above the rest */
+	if (K1H_PRIO == 1 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(2);
+	if (K1H_PRIO == 2 && wv == NWV - 1) __builtin_amdgcn_s_setprio(3);
+	if (K1H_PRIO == 3) { if (wv == NWV - 1) __builtin_amdgcn_s_setprio(3); else if (wv >= NWV / 2) __builtin_amdgcn_s_setprio(2); }
+	if (K1H_PRIO == 4 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(1);
+	if (K1H_PRIO == 5 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(3);
+	if (K1H_PRIO == 6 && wv < NWV / 2) __builtin_amdgcn_s_setprio(2);		/* (the mirror image of 1) */
+#endif
 	uint32_t done = 0;						/* spectra this cluster has finished */
 	uint32_t round = 0;						/* tiles this cluster has taken */
 
@@ -1976,25 +2023,34 @@ void k1h_fused(const K1Params p)
 	 * residues in LDS (a wave gathering its own 16-byte pieces straight from memory touches every line eight times over: measured
 	 * +205 us per frame against +37).  Two buffers: spectrum u of a tile in buffer u & 1.
 	 * fp32 IQ (not a BASELINE configuration at this length) is gathered per lane where it is used. */
-	const uint32_t iq_vo = 1024u * (unsigned)(lane >> 3) + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
-	const int in_rd  = ia * 32 + ((wv ^ (ia & 7)) << 2) + sa;	/* + 512 j: row m = ia + 16 j, residue 4 wave + sa (dwords) */
+	/* (16 residues per member: rows of 64 B, one wave-instruction lands 16 of them; piece pc of row m at slot 4 m + (pc ^ ((m >> 2) & 3)):
+	 * the 64 lanes of a read -- 16 rows x the 4 dwords of one piece -- then fall into 64 different banks) */
+	constexpr int kRowsPerDma = 256 / kRpm;			/* rows one wave-instruction lands: 8 / 16 */
+	const uint32_t iq_vo = kRpm == 32 ? 1024u * (unsigned)(lane >> 3) + 16u * (unsigned)((lane & 7) ^ ((lane >> 3) & 7))
+	                                  : 1024u * (unsigned)(lane >> 2) + 16u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+	const int in_rd  = kRpm == 32 ? ia * 32 + ((wv ^ (ia & 7)) << 2) + sa	/* + kRpm * 16 j: row m = ia + 16 j, residue 4 wave + sa (dwords) */
+	                              : ia * 16 + ((wv ^ ((ia >> 2) & 3)) << 2) + sa;
 	const uint32_t inb_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)inb;
 	if (PROBE_K1H(p) & 2)			/* (measurement only: noise-like input that is never loaded) */
-		for (int e = tid; e < 2 * kInLen; e += 512)
+		for (int e = tid; e < 2 * kInLen; e += NT)
 			inb[e] = ((0x211fu + 977u * e) & 0x3fffu) | 0x20000000u | (((0x2c11u + 131u * e) & 0x3fffu) << 16) | ((e & 1u) << 15) | ((e & 2u) << 30);
-	auto fetch_iq = [&](int t, int buf) {		/* row groups g = wave, wave + 7, ... < 32 (8 rows each) into buffer `buf`; the last wave
+	auto fetch_iq = [&](int t, int buf) {		/* row groups g = wave, wave + NWV - 1, ... (256 dwords each) into buffer `buf`; the last wave
 							 * requests nothing: it polls the cluster counters, and a poll returns behind whatever
 							 * its wave has in flight */
-		if (!HALF || (PROBE_K1H(p) & 2) || wv == 7)
+#ifndef K1H_FETCHW
+#define K1H_FETCHW (K1H_SPOLL ? NWV : NWV - 1)		/* (K1H_SPOLL: nobody polls through the vector path, every wave may fetch) */
+#endif
+		constexpr int kFetchWaves = K1H_FETCHW;
+		if (!HALF || (PROBE_K1H(p) & 2) || wv >= kFetchWaves)
 			return;
 		if (PROBE_K1H(p) & 32) t = gc;	/* (measurement only: the same rows again and again) */
 		/* global_load_lds_dwordx4 by hand: the compiler parks every LDS read and every __syncthreads() that follows an LDS-DMA it
 		 * knows about behind s_waitcnt vmcnt(0) -- the request would be waited for at the very next barrier instead of an iteration
 		 * later.  Whoever reads the buffer is behind an explicit `s_waitcnt vmcnt(..)` of the requesting wave and a barrier. */
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + 32 * member;
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + kRpm * member;
 #pragma unroll 1
-		for (int g = wv; g < 32; g += 7) {
-			const uint32_t *sk = src + 2048 * g;						/* 8 rows of 1 KiB */
+		for (int g = wv; g < kRpm; g += kFetchWaves) {
+			const uint32_t *sk = src + 256 * kRowsPerDma * g;				/* 8 / 16 rows of 1 KiB */
 			const uint32_t la = inb_lds + 4u * (unsigned)(buf * kInLen + 256 * g);
 			uint32_t keep;
 			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 " K1H_IQ_MOD "\n\ts_mov_b32 m0, %0"
@@ -2011,7 +2067,7 @@ void k1h_fused(const K1Params p)
 			const int j = K1H_PAIR(jo);
 			v2f xv;
 			if (HALF) {
-				const uint32_t raw = inb[buf * kInLen + in_rd + 512 * j];
+				const uint32_t raw = inb[buf * kInLen + in_rd + 16 * kRpm * j];
 				const h2 h = __builtin_bit_cast(h2, raw);
 				xv = v2f{ (float)h.x, (float)h.y };		/* v_cvt_f32_f16: exact */
 			} else if (PROBE_K1H(p) & 2) {
@@ -2096,138 +2152,11 @@ void k1h_fused(const K1Params p)
 	if (tile >= ntiles)
 		break;
 	const int t0 = tile * p.tile;
-	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
-	fetch_iq(t0, 0);
-	if (1 < p.tile)
-		fetch_iq(t0 + 1, 1);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	wg_barrier_lds();
-	stage_a1(t0, 0);
-	stage_a1x();
-	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
-	if (2 < p.tile)
-		fetch_iq(t0 + 2, 0);
-	stage_a2();
 	float live[16], vmax[16];
 	uint32_t plo[16], phi[16];
 #pragma unroll
 	for (int c = 0; c < 16; c++) { live[c] = 0.0f; vmax[c] = vmax_init; plo[c] = 0; phi[c] = 0; }
-
-	/* The loop is skewed: while spectrum u's blocks travel to the L2 (stores), to the other members (cluster wait) and back (loads),
-	 * the same threads run stage A of spectrum u + 1 -- its first pass between the stores and the arrival at the cluster barrier,
-	 * its second between the loads of the intermediate and their use. */
-#pragma unroll 1
-	for (int u = 0; u < p.tile; u++) {
-		const int t = t0 + u;
-		const bool more = (u + 1 < p.tile);
-
-		K1H_STAMP(0);		/* loop overhead, tile claim (first spectrum of a tile) */
-		/* (every member has read the previous spectrum out of the intermediate: the last wave looked before its epilogue)
-		 * every read of the stage-B exchange array is done -- stage A writes the same memory */
-		wg_barrier_lds();
-		K1H_STAMP(1);		/* top barrier: waiting for the work-group's slowest wave */
-		if (!(PROBE_K1H(p) & 8)) {
-			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
-			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
-			 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
-#pragma unroll
-			for (int jj = 0; jj < 16; jj++)
-				bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, 65536u * (jj >> 1));
-		}
-		if (more)
-			stage_a1(t + 1, (u + 1) & 1);			/* (while the stores travel) */
-		K1H_STAMP(2);		/* intermediate stores issued + first pass of the next spectrum */
-		/* this wave's blocks are in the L2 (and the input rows it requested most of an iteration ago in LDS) */
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		K1H_STAMP(3);		/* waiting for the stores' acknowledgements (and the IQ requested an iteration ago) */
-		wg_barrier_lds();
-		if (tid == 0)
-			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		K1H_STAMP(4);		/* barrier + arrival */
-		if (more) {
-			if (K1H_SPLIT != 3)
-				stage_a1x();				/* (while the arrivals travel) */
-			if (K1H_SPLIT == 0)
-				stage_a2_ab();				/* second pass, stages A and B (C and D: beside the loads below) */
-			else if (K1H_SPLIT == 2)
-				stage_a2();
-		}
-
-		K1H_STAMP(5);		/* transpose (+ what of the second pass runs here) */
-		if (tid == 0 && !(PROBE_K1H(p) & 1)) {
-			uint32_t spins = 0;
-			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * (done + 1)) < 0) {
-				if (++spins > kSpinLimit) { *p.sync_err = 0x80000003u; break; }
-				__builtin_amdgcn_s_sleep(1);
-			}
-		}
-		wg_barrier_lds();
-		asm volatile("" ::: "memory");
-		K1H_STAMP(6);		/* cluster barrier: poll + work-group barrier */
-
-		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
-		v2f r[16];
-		if (!(PROBE_K1H(p) & 8)) {
-			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
-#pragma unroll
-			for (int jo = 0; jo < 16; jo++)
-				r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * K1H_PAIR(jo));
-		} else {
-#pragma unroll
-			for (int j = 0; j < 16; j++)
-				r[j] = ra[j];
-		}
-		if (more) {						/* (while the loads travel) */
-			if (K1H_SPLIT == 0)
-				stage_a2_cd();
-			else if (K1H_SPLIT == 1)
-				stage_a2();
-			else if (K1H_SPLIT == 3) {
-				stage_a1x();
-				stage_a2();
-			}
-		}
-		K1H_STAMP(7);		/* loads of the intermediate issued + second pass of the next spectrum */
-		pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
-#if K1H_TIMING
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-		K1H_STAMP(8);		/* third pass, stages A and B: includes the wait for the loads */
-		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (two barriers ago); it is
-		 * waited for by the `vmcnt(0)` of the NEXT iteration.  Requested only now that the loads of the intermediate have been used:
-		 * loads return in order, and these come from HBM */
-		if (u + 3 < p.tile)
-			fetch_iq(t + 3, (u + 1) & 1);
-		pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
-#pragma unroll
-		for (int jj = 0; jj < 16; jj++)
-			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
-		K1H_STAMP(9);		/* IQ request + third pass, stages C and D + exchange stores */
-		wg_barrier_lds();
-		if (tid == 0)							/* everybody's loads of the intermediate have landed */
-			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		done++;
-		K1H_STAMP(10);		/* exchange barrier */
-#pragma unroll
-		for (int jo = 0; jo < 16; jo++)
-			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
-		pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
-		pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
-
-		K1H_STAMP(11);		/* exchange loads + fourth pass */
-		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
-		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them.  (Round 5, K1H_TIMING build: the
-		 * ~2000 cycles this wave spends here per spectrum are the spread between the cluster's members, not a round trip -- requesting
-		 * the counter one pass EARLIER and looking at the answer here returned "not yet" and cost 50 us per frame on top.) */
-		if (tid == 448 && !(PROBE_K1H(p) & 1)) {
-			uint32_t spins = 0;
-			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 8u * done) < 0) {
-				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
-				__builtin_amdgcn_s_sleep(1);
-			}
-		}
-
-		K1H_STAMP(12);		/* "everyone has read the intermediate" poll (last wave only) */
+	auto epilogue = [&](v2f (&r)[16], const int t, const int u) {
 		if (WRITE_FFT) {
 #pragma unroll
 			for (int c = 0; c < 16; c++)
@@ -2287,8 +2216,290 @@ void k1h_fused(const K1Params p)
 				plo[c] = 0;
 			}
 		}
+	};
+#if K1H_SCHED == 2
+	/* ---- the schedule of round 6 (K1H_SCHED == 2) ------------------------------------------------------------------------------
+	 * Until round 5 a spectrum's hand-over was IN LINE: stores -> acknowledgements -> cluster barrier -> loads -> "everybody has
+	 * loaded" -> the next spectrum's stores, each step waiting for the slowest of the cluster's members (K1H_TIMING: ~6 000 of
+	 * 16 000 cycles per spectrum at barriers and polls; an ablation build without any memory access still took 2/3 of the time).
+	 * Now both questions are asked half an iteration AFTER the event they ask about:
+	 *   top of iteration u      "has every wave of the cluster stored spectrum u?"   -- the stores went out in the MIDDLE of iteration u - 1
+	 *   middle of iteration u   "has every wave loaded spectrum u?" (one buffer)     -- the loads were requested at the TOP of iteration u
+	 * so members may drift by almost half an iteration before anybody waits.  Every wave asks for itself through the scalar data
+	 * path (s_dcache_inv + s_load_dword: does not queue behind the wave's vector memory operations) and arrives for itself (64 arrivals per
+	 * spectrum and counter), so no work-group barrier is spent on the cluster.  Three work-group barriers per spectrum remain, all
+	 * for LDS hazards: B1 stage A's transposes read -> stage B's exchange written (same memory; also: the IQ buffer is free),
+	 * B2 the exchange itself, B3 exchange read -> the next spectrum's transposes written (also: the IQ requested an iteration ago
+	 * is visible to every wave).  Stage A of spectrum u + 1 runs as ONE piece beside the loads of spectrum u. */
+	static_assert(K1H_SPOLL, "K1H_SCHED == 2: every wave requests the same number of IQ pieces (stores_acked counts them)");
+	constexpr uint32_t kArr = 64;					/* arrivals per spectrum and counter: every wave of every member */
+	auto poll = [&](const uint32_t *cnt, uint32_t target, uint32_t err) {
+		if (PROBE_K1H(p) & 1)
+			return;
+		uint32_t spins = 0;
+		while ((int)(sload_fresh(cnt) - target) < 0) {
+			if (++spins > kSpinLimit) { if (lane == 0) *p.sync_err = err; break; }	/* fail the call, not the GPU */
+			__builtin_amdgcn_s_sleep(1);
+		}
+	};
+	auto arrive = [&](uint32_t *cnt) {
+		if (lane == 0)
+			__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
+	/* stage A's results of the cluster's spectrum number `sn` (counted from the launch's start) go to buffer sn % K1H_NBUF */
+	auto store_a = [&](uint32_t sn) {
+		/* the buffer is free: every wave of every member has loaded the spectrum that was in it */
+		poll(c_b, kArr * (sn + 1 - K1H_NBUF), 0x80000002u);
+		if (PROBE_K1H(p) & 8)
+			return;
+		const uint32_t bo = (K1H_NBUF == 2 && (sn & 1)) ? (uint32_t)(4 * N * 8) : 0u;		/* second buffer: the slot of cluster gc + 4 */
+		/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
+		 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
+		 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++) {
+			if (kRpm == 32) bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, bo + 65536u * (jj >> 1));
+			else            bst_v2f<0>(ra[R16_PERM(jj)], rs_w, wst0, bo + 32768u * jj);	/* (one instruction: four residues = 512 B in a row) */
+		}
+	};
+	/* this wave's stores are in the L2: what it has requested SINCE (the IQ of a later spectrum, HBM latency) may stay in flight */
+	auto stores_acked = [&](bool fetched) {
+		if (HALF && fetched) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRpm / (K1H_SPOLL ? NWV : NWV - 1)) : "memory");
+		else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	};
+
+	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
+	fetch_iq(t0, 0);
+	if (1 < p.tile)
+		fetch_iq(t0 + 1, 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	wg_barrier_lds();
+	stage_a1(t0, 0);
+	stage_a1x();
+	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
+	stage_a2();
+	store_a(done);
+	if (2 < p.tile)
+		fetch_iq(t0 + 2, 0);
+	stores_acked(2 < p.tile);
+	arrive(c_a);
+
+#pragma unroll 1
+	for (int u = 0; u < p.tile; u++) {
+		const int t = t0 + u;
+		const bool more = (u + 1 < p.tile);
+
+		K1H_STAMP(0);		/* loop overhead, tile claim (first spectrum of a tile) */
+		poll(c_a, kArr * (done + 1), 0x80000003u);		/* every wave of the cluster has stored its part of this spectrum */
+		K1H_STAMP(1);		/* "spectrum stored?" */
+
+		/* ================= stage B: offsets kk = kRpm member .. ================= */
+		v2f r[16];
+		if (!(PROBE_K1H(p) & 8)) {
+			const uint32_t bo = (K1H_NBUF == 2 && (done & 1)) ? (uint32_t)(4 * N * 8) : 0u;
+			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
+#pragma unroll
+			for (int jo = 0; jo < 16; jo++)
+				r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, bo + (uint32_t)(2048 * kRpm) * member + (uint32_t)(128 * kRpm) * K1H_PAIR(jo));
+		} else {
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				r[j] = ra[j];
+		}
+		K1H_STAMP(2);		/* loads of the intermediate issued */
+		if (more) {						/* (while the loads travel: all of the next spectrum's stage A) */
+			stage_a1(t + 1, (u + 1) & 1);
+			stage_a1x();
+			stage_a2();
+		}
+		K1H_STAMP(3);		/* stage A of the next spectrum */
+		pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
+#if K1H_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		K1H_STAMP(4);		/* third pass, stages A and B: includes the wait for the loads */
+		pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
+		arrive(c_b);						/* this wave's loads of the intermediate have landed */
+		K1H_STAMP(5);		/* third pass, stages C and D */
+		wg_barrier_lds();					/* B1 */
+		K1H_STAMP(6);		/* barrier B1 */
+		if (more)
+			store_a(done + 1);
+		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (B1); requested BEHIND the stores
+		 * (their acknowledgements are waited for below, this is not) and behind the loads of the intermediate (loads return in order,
+		 * and these come from HBM); landed and visible at B3 of the next iteration */
+		if (u + 3 < p.tile)
+			fetch_iq(t + 3, (u + 1) & 1);
+		K1H_STAMP(7);		/* "buffer free?" + stores of the next spectrum's stage A + IQ request */
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
+		K1H_STAMP(8);		/* exchange stores */
+		wg_barrier_lds();					/* B2 */
+		K1H_STAMP(9);		/* exchange barrier B2 */
+#pragma unroll
+		for (int jo = 0; jo < 16; jo++)
+			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
+		pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
+		pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
+		K1H_STAMP(10);		/* exchange loads + fourth pass */
+		if (more) {
+			stores_acked(u + 3 < p.tile);
+			arrive(c_a);
+		}
+		done++;
+		K1H_STAMP(11);		/* stores acknowledged + arrival */
+		wg_barrier_lds();					/* B3 */
+		K1H_STAMP(12);		/* barrier B3 */
+		epilogue(r, t, u);
 		K1H_STAMP(13);		/* epilogue */
 	}
+#else
+	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
+	fetch_iq(t0, 0);
+	if (1 < p.tile)
+		fetch_iq(t0 + 1, 1);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	wg_barrier_lds();
+	stage_a1(t0, 0);
+	stage_a1x();
+	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
+	if (2 < p.tile)
+		fetch_iq(t0 + 2, 0);
+	stage_a2();
+
+	/* The loop is skewed: while spectrum u's blocks travel to the L2 (stores), to the other members (cluster wait) and back (loads),
+	 * the same threads run stage A of spectrum u + 1 -- its first pass between the stores and the arrival at the cluster barrier,
+	 * its second between the loads of the intermediate and their use. */
+#pragma unroll 1
+	for (int u = 0; u < p.tile; u++) {
+		const int t = t0 + u;
+		const bool more = (u + 1 < p.tile);
+
+		K1H_STAMP(0);		/* loop overhead, tile claim (first spectrum of a tile) */
+		/* (every member has read the previous spectrum out of the intermediate: the last wave looked before its epilogue)
+		 * every read of the stage-B exchange array is done -- stage A writes the same memory */
+		if (K1H_SPOLL) {
+			/* every member has read the previous spectrum out of the intermediate? */
+			if (!(PROBE_K1H(p) & 1)) {
+				uint32_t spins = 0;
+				while ((int)(sload_fresh(c_b) - (uint32_t)kMem * done) < 0) {
+					if (++spins > kSpinLimit) { if (lane == 0) *p.sync_err = 0x80000002u; break; }
+					__builtin_amdgcn_s_sleep(1);
+				}
+			}
+		} else {
+			wg_barrier_lds();
+		}
+		K1H_STAMP(1);		/* top barrier: waiting for the work-group's slowest wave (K1H_SPOLL: this wave's own look at the counter) */
+		if (!(PROBE_K1H(p) & 8)) {
+			/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
+			 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
+			 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
+#pragma unroll
+			for (int jj = 0; jj < 16; jj++) {
+				if (kRpm == 32) bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, 65536u * (jj >> 1));
+				else            bst_v2f<0>(ra[R16_PERM(jj)], rs_w, wst0, 32768u * jj);	/* (one instruction: four residues = 512 B in a row) */
+			}
+		}
+		if (more)
+			stage_a1(t + 1, (u + 1) & 1);			/* (while the stores travel) */
+		K1H_STAMP(2);		/* intermediate stores issued + first pass of the next spectrum */
+		/* this wave's blocks are in the L2 (and the input rows it requested most of an iteration ago in LDS) */
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		K1H_STAMP(3);		/* waiting for the stores' acknowledgements (and the IQ requested an iteration ago) */
+		wg_barrier_lds();
+		if (tid == 0)
+			__hip_atomic_fetch_add(c_a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		K1H_STAMP(4);		/* barrier + arrival */
+		if (more) {
+			if (K1H_SPLIT != 3)
+				stage_a1x();				/* (while the arrivals travel) */
+			if (K1H_SPLIT == 0)
+				stage_a2_ab();				/* second pass, stages A and B (C and D: beside the loads below) */
+			else if (K1H_SPLIT == 2)
+				stage_a2();
+		}
+
+		K1H_STAMP(5);		/* transpose (+ what of the second pass runs here) */
+		if (tid == 0 && !(PROBE_K1H(p) & 1)) {
+			uint32_t spins = 0;
+			while ((int)(__hip_atomic_load(c_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (uint32_t)kMem * (done + 1)) < 0) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000003u; break; }
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
+		wg_barrier_lds();
+		asm volatile("" ::: "memory");
+		K1H_STAMP(6);		/* cluster barrier: poll + work-group barrier */
+
+		/* ================= stage B: offsets kk = 32 member .. + 31 ================= */
+		v2f r[16];
+		if (!(PROBE_K1H(p) & 8)) {
+			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
+#pragma unroll
+			for (int jo = 0; jo < 16; jo++)
+				r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, (uint32_t)(2048 * kRpm) * member + (uint32_t)(128 * kRpm) * K1H_PAIR(jo));
+		} else {
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				r[j] = ra[j];
+		}
+		if (more) {						/* (while the loads travel) */
+			if (K1H_SPLIT == 0)
+				stage_a2_cd();
+			else if (K1H_SPLIT == 1)
+				stage_a2();
+			else if (K1H_SPLIT == 3) {
+				stage_a1x();
+				stage_a2();
+			}
+		}
+		K1H_STAMP(7);		/* loads of the intermediate issued + second pass of the next spectrum */
+		pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
+#if K1H_TIMING
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		K1H_STAMP(8);		/* third pass, stages A and B: includes the wait for the loads */
+		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (two barriers ago); it is
+		 * waited for by the `vmcnt(0)` of the NEXT iteration.  Requested only now that the loads of the intermediate have been used:
+		 * loads return in order, and these come from HBM */
+		if (u + 3 < p.tile)
+			fetch_iq(t + 3, (u + 1) & 1);
+		pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
+#pragma unroll
+		for (int jj = 0; jj < 16; jj++)
+			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
+		K1H_STAMP(9);		/* IQ request + third pass, stages C and D + exchange stores */
+		wg_barrier_lds();
+		if (tid == 0)							/* everybody's loads of the intermediate have landed */
+			__hip_atomic_fetch_add(c_b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		done++;
+		K1H_STAMP(10);		/* exchange barrier */
+#pragma unroll
+		for (int jo = 0; jo < 16; jo++)
+			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
+		pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
+		pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
+
+		K1H_STAMP(11);		/* exchange loads + fourth pass */
+		/* every member has read this spectrum out of the intermediate?  (they said so about a pass ago.)  Asked here because this
+		 * wave has nothing in flight now: behind the epilogue's stores the answer would wait for them.  (Round 5, K1H_TIMING build: the
+		 * ~2000 cycles this wave spends here per spectrum are the spread between the cluster's members, not a round trip -- requesting
+		 * the counter one pass EARLIER and looking at the answer here returned "not yet" and cost 50 us per frame on top.) */
+		if (!K1H_SPOLL && tid == NT - 64 && !(PROBE_K1H(p) & 1)) {
+			uint32_t spins = 0;
+			while ((int)(__hip_atomic_load(c_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (uint32_t)kMem * done) < 0) {
+				if (++spins > kSpinLimit) { *p.sync_err = 0x80000002u; break; }
+				__builtin_amdgcn_s_sleep(1);
+			}
+		}
+
+		K1H_STAMP(12);		/* "everyone has read the intermediate" poll (last wave only) */
+		epilogue(r, t, u);
+		K1H_STAMP(13);		/* epilogue */
+	}
+#endif
 	if (!(PROBE_K1H(p) & 4)) {
 		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
 #pragma unroll
@@ -2301,8 +2512,8 @@ void k1h_fused(const K1Params p)
 		           rs_part, 8u * ucol0, (uint32_t)tile * (uint32_t)(N * 8) + 32768u * c);
 	}
 #if K1H_TIMING
-	if (p.dbg && lane == 0 && (wv == 0 || wv == 3 || wv == 7)) {
-		const int slot = (wv == 0) ? 0 : (wv == 3) ? 1 : 2;
+	if (p.dbg && lane == 0 && (wv == 0 || wv == NWV / 2 - 1 || wv == NWV - 1)) {
+		const int slot = (wv == 0) ? 0 : (wv == NWV / 2 - 1) ? 1 : 2;
 		for (int i = 0; i < 16; i++)
 			p.dbg[((size_t)blockIdx.x * 3 + slot) * 16 + i] = hacc[i];
 	}
@@ -2310,32 +2521,37 @@ void k1h_fused(const K1Params p)
 	leave();
 }
 
+template <int NWV>
+static hipError_t launch_k1h_form(const K1Params &p0, hipStream_t s)
+{
+	typedef void (*k1h_fn)(const K1Params);
+	static const k1h_fn fn[4] = { k1h_fused<false, false, NWV>, k1h_fused<true, false, NWV>, k1h_fused<false, true, NWV>, k1h_fused<true, true, NWV> };
+	constexpr size_t lds = K1hGeom<NWV>::kLds;
+	/* (the attribute belongs to the function object of the CURRENT device: once per device, not once per process) */
+	static unsigned long long attr_dev = 0;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+		return hipErrorInvalidDevice;
+	if (!(attr_dev >> dev & 1)) {
+		for (int i = 0; i < 4; i++) {
+			const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			if (e != hipSuccess)
+				return e;
+		}
+		attr_dev |= 1ull << dev;
+	}
+	/* (the counters in p0.sync are zero: cleared at allocation, and by the last work-group of every launch) */
+	/* 32 clusters: 8 work-groups of 8 waves, one per CU -- or 16 work-groups of 4 waves, two per CU */
+	hipLaunchKernelGGL(fn[(p0.iq_half ? 1 : 0) | (p0.fft_out ? 2 : 0)], dim3(256 * 8 / NWV), dim3(64 * NWV), lds, s, p0);
+	return hipGetLastError();
+}
+
 static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 {
 	/* tiles of 4 .. 32 spectra (whole quads of low bytes, the 9th bits of a tile in one dword); tile index: 20 bits of the claim word */
 	if (!p0.sync || !p0.scratch || p0.tile < 4 || p0.tile > 32 || (p0.tile & 3) || p0.total % p0.tile || p0.total / p0.tile >= (1 << 20))
 		return hipErrorInvalidValue;
-	static bool attr_f = false;
-	if (!attr_f) {
-		const void *fn[4] = { reinterpret_cast<const void *>(k1h_fused<false, false>), reinterpret_cast<const void *>(k1h_fused<true, false>),
-		                      reinterpret_cast<const void *>(k1h_fused<false, true>), reinterpret_cast<const void *>(k1h_fused<true, true>) };
-		for (int i = 0; i < 4; i++) {
-			const hipError_t e = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hLds);
-			if (e != hipSuccess)
-				return e;
-		}
-		attr_f = true;
-	}
-	/* (the counters in p0.sync are zero: cleared at allocation, and by the last work-group of every launch) */
-	/* 32 clusters of 8 work-groups, one work-group (8 waves) per CU */
-	if (p0.iq_half) {
-		if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<true, true>), dim3(256), dim3(512), kK1hLds, s, p0);
-		else            hipLaunchKernelGGL((k1h_fused<true, false>), dim3(256), dim3(512), kK1hLds, s, p0);
-	} else {
-		if (p0.fft_out) hipLaunchKernelGGL((k1h_fused<false, true>), dim3(256), dim3(512), kK1hLds, s, p0);
-		else            hipLaunchKernelGGL((k1h_fused<false, false>), dim3(256), dim3(512), kK1hLds, s, p0);
-	}
-	return hipGetLastError();
+	return p0.k1h_waves == 8 ? launch_k1h_form<8>(p0, s) : launch_k1h_form<4>(p0, s);
 }
 
 
