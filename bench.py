@@ -32,7 +32,9 @@ Other BASELINE configurations: --config C3 (8192-pt FFT, 50 % overlap fused into
 4096, 512 bins) and --config C5 (65536-pt FFT, fp16 IQ, 512 bins, the per-GPU share of a sharded
 frame) emit the same JSON shape with their own workload string and roofline convention.  The default
 run (C2, one GPU) ALSO measures C3 (20 steps) and C5 (200 steps: a C5 step is one 0.29 ms frame), in the same process, after the
-headline, and reports them inside the one JSON line as `other_configs` (--no-other-configs skips them).
+headline, and reports them inside the one JSON line as `other_configs` (--no-other-configs skips them), followed by
+`other_configs.sink`: the PCIe-INCLUSIVE rates of the drop-in path (work() -> FIFO -> H2D -> kernels, and plain fosphor_process()
+calls of 1 Mi host samples), 2 s each, as MSamples/s and as a fraction of the Gen5 x16 link -- reported, never `value`.
 
 roofline: the dominant kernel is K1 (fft_bin), bound by the HBM read of the IQ stream (8 B per
 sample, 4 B for fp16 IQ).  K1s of consecutive sub-launches run on alternating streams and overlap
@@ -94,6 +96,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default C2 run on one GPU: do not measure C3 / C5 afterwards (other_configs in the JSON line)")
     ap.add_argument("--other-steps", type=int, default=20, help="steps of the other_configs pass (C3; C5 runs ten times as many)")
+    ap.add_argument("--sink-seconds", type=float, default=2.0, help="seconds of each PCIe-inclusive leg of other_configs.sink")
     ap.add_argument("--strict-ordering", action="store_true", help="keep stream ordering between calls (default: relaxed, "
                     "the input ring is never rewritten)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -103,6 +106,21 @@ def parse():
 # ---------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: start one as a child (no GPU call has been made in this process)
 # ---------------------------------------------------------------------------------------------------
+
+def scaling_record_guard(world, transport, exchange_ranks_per_rank, test_hook=False):
+    """A line measured on N > 1 ranks is a SCALING record (the driver computes efficiency from it): it must have exchanged through
+    the native RCCL transport, and the library's communicator must span all N ranks on every rank (ncclCommCount).  Returns the
+    reason the record is invalid, or None.  test_hook: the ranks share one GPU over gloo on purpose (tests/test_gpu_dist.py):
+    the torch transport is then what is being tested."""
+    if world <= 1 or test_hook:
+        return None
+    if not str(transport).startswith("native RCCL"):
+        return "%d ranks exchanged through '%s', not the native RCCL transport: not a scaling record" % (world, transport)
+    bad = [(r, n) for r, n in enumerate(exchange_ranks_per_rank) if int(n) != world]
+    if len(exchange_ranks_per_rank) != world or bad:
+        return "the exchange spans %s ranks per rank, not %d on every rank: not a scaling record" % (list(exchange_ranks_per_rank), world)
+    return None
+
 
 def launcher_command(n_gpus, argv, port):
     """The command `bench.py --gpus N` starts when no launcher did (pure function: tests/test_boundary_cpu.py)."""
@@ -611,6 +629,72 @@ def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
     return out
 
 
+
+PCIE_GEN5_X16_GBS = 63.0	# Gen5 x16, one direction, before protocol overhead
+
+
+def measure_sink(ctx, seconds=2.0):
+    """PCIe-INCLUSIVE rates of the drop-in path (SURVEY 8d's "second number with H2D included"; never `value`), C1/C2 geometry
+    (1024-pt FFT, the reference's 128 bins), host samples in pageable memory as a GNU Radio buffer would be:
+      work_fifo      gr::fosphor::base_sink_c::work() -> fifo -> render(): fosphor_process() (base_sink_c_impl.cc:130-201,432-462)
+                     as the GNU-Radio-free runtime does it (fosphor_sink.cpp: pinned FIFO, uploads on their own stream, up to 8 batches
+                     per call), fed by a native thread in work() calls of 64 Ki samples for >= `seconds`;
+      process_calls  plain fosphor_process(self, samples, 1 Mi) calls from host memory (the literal reference call shape,
+                     base_sink_c_impl.cc:146-175 -> cl.c:903-910), one fosphor_draw() per 8 calls, for >= `seconds`."""
+    import ctypes as C
+    import numpy as np
+    pkg = ctx["pkg"]
+    L = pkg.load()
+    out = {"unit": "MSamples/s", "link": "PCIe Gen5 x16, %.0f GB/s one way" % PCIE_GEN5_X16_GBS,
+           "note": "host-resident fp32 IQ, H2D inside the timed region; never the headline value"}
+    n = 32 << 20						# 32 Mi samples = 256 MiB per pass
+    x = (np.random.default_rng(3).standard_normal((n, 2)) * 0.05).astype(np.float32)
+    # (a) work() -> FIFO -> upload -> kernels
+    s = L.fosphor_amd_sink_new_len(1 << 24)
+    try:
+        if L.fosphor_amd_sink_start(s) != 1:
+            raise RuntimeError("sink did not start")
+        if L.fosphor_amd_sink_feed(s, x.ctypes.data, n, 64 * 1024, 1) < 0:	# warm-up (boot, staging buffers)
+            raise RuntimeError("sink consumed nothing")
+        reps, dt = 0, 0.0
+        while dt < seconds:
+            d = L.fosphor_amd_sink_feed(s, x.ctypes.data, n, 64 * 1024, 4)
+            if d < 0:
+                raise RuntimeError("sink stalled")
+            dt += d
+            reps += 4
+        v = n * reps / dt / 1e6
+        out["work_fifo"] = {"value": v, "seconds": dt, "samples": n * reps, "frac_of_link": v * 8e6 / (PCIE_GEN5_X16_GBS * 1e9),
+                            "dropped": int(L.fosphor_amd_sink_dropped(s)), "work_call_samples": 64 * 1024, "fifo_samples": 1 << 24}
+        L.fosphor_amd_sink_stop(s)
+    finally:
+        L.fosphor_amd_sink_free(s)
+    # (b) fosphor_process() per 1 Mi samples
+    f = pkg.Fosphor()
+    try:
+        m = 1 << 20
+        for k in range(8):
+            assert f.process(x[k * m:(k + 1) * m]) == 0
+        f.draw()
+        t0 = time.perf_counter()
+        calls = 0
+        while True:
+            for k in range(8):
+                o = ((calls + k) % (n // m)) * m
+                if f.process(x[o:o + m]) != 0:
+                    raise RuntimeError("fosphor_process failed")
+            f.draw()
+            calls += 8
+            dt = time.perf_counter() - t0
+            if dt >= seconds:
+                break
+        v = calls * m / dt / 1e6
+        out["process_calls"] = {"value": v, "seconds": dt, "samples": calls * m, "frac_of_link": v * 8e6 / (PCIE_GEN5_X16_GBS * 1e9),
+                                "call_samples": m, "draw_every_calls": 8}
+    finally:
+        f.close()
+    return out
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -663,9 +747,21 @@ def main():
                 others["C3"]["four_batch_call_value"] = c3_4["value"]
         except Exception as e:
             sys.stderr.write("bench.py: C3 with 4-batch calls: %s\n" % e)
+        try:
+            others["sink"] = measure_sink(ctx, args.sink_seconds)
+        except Exception as e:
+            others["sink"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if out is not None:
             out["other_configs"] = others
 
+    guard = None
+    if rank == 0 and out is not None:
+        # no silent fallback in a scaling record: anything but the native exchange over all N ranks fails the run (exit code 3)
+        guard = scaling_record_guard(world, out["config"].get("transport"), out["config"].get("exchange_ranks_per_rank", []),
+                                     test_hook=os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl") != "nccl")
+        if guard:
+            out["invalid"] = guard
+            sys.stderr.write("bench.py: %s\n" % guard)
     if rank == 0 and out is not None:
         if world == 1 and not args.no_cpu_baseline and args.config == "C2":
             out["cpu_baseline"] = cpu_baseline((args.bins or CONFIGS["C2"]["bins"]), args.cpu_seconds)
@@ -678,6 +774,8 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if guard:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

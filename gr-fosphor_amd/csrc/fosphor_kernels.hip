@@ -1397,6 +1397,8 @@ static __device__ __forceinline__ void wg_barrier_lds()
 #define K1W_STAMP(i) do { } while (0)
 #endif
 
+constexpr int kK1wIdxStores = 16;	/* index stores a thread issues per ODD spectrum (one dword per column and pair of spectra): the immediate of the
+					 * hand-written wait for the IQ requested before them */
 template <int SHIFT>
 __global__ __launch_bounds__(512, 2)
 void k1w_fft_bin(const K1Params p)
@@ -1578,8 +1580,11 @@ void k1w_fft_bin(const K1Params p)
 #define K1W_Q16 "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), \
 		"+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15])
 		/* (ONE statement, the choice inside it: two statements under an if made the compiler copy q -- before the wait) */
-		asm volatile("s_cmp_eq_u32 %16, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(16)\n\ts_branch 2f\n1:\ts_waitcnt vmcnt(0)\n2:"
-		             : K1W_Q16 : "s"(__builtin_amdgcn_readfirstlane((!K1W_P(8) && (g & 1) && g >= 3) ? 1 : 0)) : "scc");
+		/* (kK1wIdxStores: ONE constant for the wait's immediate and for what K1W_EPI issues per odd spectrum -- a change of the index
+		 * format that packs the stores must change both; tools/check_k1w_loads.py counts the stores of the compiled loop against it) */
+		static_assert(kK1wIdxStores == 16, "the counted wait below and K1W_EPI's index stores (one dword per column and pair of spectra) go together");
+		asm volatile("s_cmp_eq_u32 %16, 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%17)\n\ts_branch 2f\n1:\ts_waitcnt vmcnt(0)\n2:"
+		             : K1W_Q16 : "s"(__builtin_amdgcn_readfirstlane((!K1W_P(8) && (g & 1) && g >= 3) ? 1 : 0)), "n"(kK1wIdxStores) : "scc");
 #undef K1W_Q16
 #pragma unroll
 		for (int j = 0; j < 16; j++)
@@ -1820,11 +1825,13 @@ void k1w_fft_bin(const K1Params p)
 #ifndef K1H_SPOLL
 #define K1H_SPOLL 1
 #endif
-#ifndef K1H_SCHED
-#define K1H_SCHED 1		/* 1: the in-line hand-over of rounds 4-5; 2: hand-overs half an iteration late (round 6: built, parity-green, 25 % slower) */
-#endif
-#ifndef K1H_NBUF
-#define K1H_NBUF 1		/* intermediates per cluster (K1H_SCHED == 2): 2 = the slot of cluster gc + 4 as a second buffer (4 MiB per XCD: all of its L2) */
+/* K1H_PRIO=1 (round 6): the YOUNGER wave of each SIMD (waves 4-7 of the work-group) issues at a higher priority than the older one.  Left to the
+ * arbiter's age order the older wave of a SIMD won every tie and the younger ones reached each of the four barriers ~2 000 cycles late
+ * (K1H_TIMING builds); with the priority the other way round the halves of the work-group take turns at being early -- the early wave's stores
+ * and first pass run beside the late wave's epilogue -- and the kernel alone went from 231 to 216 us (profiles/r06_c5.md: the mirror image,
+ * priority to the OLDER half, changes nothing; levels 1 / 2 / 3 measure the same). */
+#ifndef K1H_PRIO
+#define K1H_PRIO 1
 #endif
 static __device__ __forceinline__ uint32_t sload_fresh(const uint32_t *p)
 {
@@ -1845,9 +1852,10 @@ constexpr int kXaWave = 4 * 272;		/* stage-A exchange, elements per wave: [resid
 constexpr int kThrMax  = 520;			/* exact-bin thresholds kept in LDS (n_bins + 1 <= 513 doubles) */
 constexpr int kTwRow = 9;			/* LDS twiddle tables: 8 twiddles per row, rows padded to 9 entries (72 B: 16 / 32 rows fall into different banks) */
 /* The work-group's size decides the cluster's: a work-group of NWV waves takes 4 NWV residues (stage A) / offsets (stage B) of a spectrum,
- * so 64 / NWV work-groups make a cluster.  NWV = 8: one work-group per CU, clusters of 8.  NWV = 4 (round 6): TWO work-groups per CU --
- * members of different clusters, each with its own barriers -- so the CU's two halves are at different points of the loop and one's
- * arithmetic runs beside the other's LDS / memory phases; clusters of 16. */
+ * so 64 / NWV work-groups make a cluster.  NWV = 8 is what runs: one work-group per CU, clusters of 8.  NWV = 4 -- TWO work-groups per CU,
+ * members of different clusters of 16, so that one's arithmetic could run beside the other's LDS / memory phases -- was built in round 6,
+ * parity-green, and 45-85 % SLOWER (450 against 245 us per frame: twice the members to wait for at each of a spectrum's two hand-overs,
+ * and the hand-overs are what the loop's time is made of; profiles/r06_c5.md).  The geometry stays parametrised; only NWV = 8 is instantiated. */
 template <int NWV> struct K1hGeom {
 	static constexpr int kMem   = 64 / NWV;		/* members of a cluster */
 	static constexpr int kRpm   = 4 * NWV;		/* residues = offsets per member */
@@ -2001,17 +2009,8 @@ void k1h_fused(const K1Params p)
 	const int eb_w = kkl * 257 + ib;		/* + 16 jj3: pass-3 outputs [offset][jj3][a3] */
 	const int eb_r = kkl * 257 + ib * 16;		/* + j4    : pass-4 inputs of item jj3 = ib */
 
-#ifndef K1H_PRIO
-#define K1H_PRIO 1
-#endif
-#if K1H_PRIO		/* (A/B builds) issue priority by wave: 1 = the upper half of the work-group above the lower, 2 = the last wave above the rest */
-	if (K1H_PRIO == 1 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(2);
-	if (K1H_PRIO == 2 && wv == NWV - 1) __builtin_amdgcn_s_setprio(3);
-	if (K1H_PRIO == 3) { if (wv == NWV - 1) __builtin_amdgcn_s_setprio(3); else if (wv >= NWV / 2) __builtin_amdgcn_s_setprio(2); }
-	if (K1H_PRIO == 4 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(1);
-	if (K1H_PRIO == 5 && wv >= NWV / 2) __builtin_amdgcn_s_setprio(3);
-	if (K1H_PRIO == 6 && wv < NWV / 2) __builtin_amdgcn_s_setprio(2);		/* (the mirror image of 1) */
-#endif
+	if (K1H_PRIO && wv >= NWV / 2)
+		__builtin_amdgcn_s_setprio(2);
 	uint32_t done = 0;						/* spectra this cluster has finished */
 	uint32_t round = 0;						/* tiles this cluster has taken */
 
@@ -2037,10 +2036,7 @@ void k1h_fused(const K1Params p)
 	auto fetch_iq = [&](int t, int buf) {		/* row groups g = wave, wave + NWV - 1, ... (256 dwords each) into buffer `buf`; the last wave
 							 * requests nothing: it polls the cluster counters, and a poll returns behind whatever
 							 * its wave has in flight */
-#ifndef K1H_FETCHW
-#define K1H_FETCHW (K1H_SPOLL ? NWV : NWV - 1)		/* (K1H_SPOLL: nobody polls through the vector path, every wave may fetch) */
-#endif
-		constexpr int kFetchWaves = K1H_FETCHW;
+		constexpr int kFetchWaves = K1H_SPOLL ? NWV : NWV - 1;	/* (K1H_SPOLL: nobody polls through the vector path, every wave fetches) */
 		if (!HALF || (PROBE_K1H(p) & 2) || wv >= kFetchWaves)
 			return;
 		if (PROBE_K1H(p) & 32) t = gc;	/* (measurement only: the same rows again and again) */
@@ -2217,144 +2213,6 @@ void k1h_fused(const K1Params p)
 			}
 		}
 	};
-#if K1H_SCHED == 2
-	/* ---- the schedule of round 6 (K1H_SCHED == 2) ------------------------------------------------------------------------------
-	 * Until round 5 a spectrum's hand-over was IN LINE: stores -> acknowledgements -> cluster barrier -> loads -> "everybody has
-	 * loaded" -> the next spectrum's stores, each step waiting for the slowest of the cluster's members (K1H_TIMING: ~6 000 of
-	 * 16 000 cycles per spectrum at barriers and polls; an ablation build without any memory access still took 2/3 of the time).
-	 * Now both questions are asked half an iteration AFTER the event they ask about:
-	 *   top of iteration u      "has every wave of the cluster stored spectrum u?"   -- the stores went out in the MIDDLE of iteration u - 1
-	 *   middle of iteration u   "has every wave loaded spectrum u?" (one buffer)     -- the loads were requested at the TOP of iteration u
-	 * so members may drift by almost half an iteration before anybody waits.  Every wave asks for itself through the scalar data
-	 * path (s_dcache_inv + s_load_dword: does not queue behind the wave's vector memory operations) and arrives for itself (64 arrivals per
-	 * spectrum and counter), so no work-group barrier is spent on the cluster.  Three work-group barriers per spectrum remain, all
-	 * for LDS hazards: B1 stage A's transposes read -> stage B's exchange written (same memory; also: the IQ buffer is free),
-	 * B2 the exchange itself, B3 exchange read -> the next spectrum's transposes written (also: the IQ requested an iteration ago
-	 * is visible to every wave).  Stage A of spectrum u + 1 runs as ONE piece beside the loads of spectrum u. */
-	static_assert(K1H_SPOLL, "K1H_SCHED == 2: every wave requests the same number of IQ pieces (stores_acked counts them)");
-	constexpr uint32_t kArr = 64;					/* arrivals per spectrum and counter: every wave of every member */
-	auto poll = [&](const uint32_t *cnt, uint32_t target, uint32_t err) {
-		if (PROBE_K1H(p) & 1)
-			return;
-		uint32_t spins = 0;
-		while ((int)(sload_fresh(cnt) - target) < 0) {
-			if (++spins > kSpinLimit) { if (lane == 0) *p.sync_err = err; break; }	/* fail the call, not the GPU */
-			__builtin_amdgcn_s_sleep(1);
-		}
-	};
-	auto arrive = [&](uint32_t *cnt) {
-		if (lane == 0)
-			__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	};
-	/* stage A's results of the cluster's spectrum number `sn` (counted from the launch's start) go to buffer sn % K1H_NBUF */
-	auto store_a = [&](uint32_t sn) {
-		/* the buffer is free: every wave of every member has loaded the spectrum that was in it */
-		poll(c_b, kArr * (sn + 1 - K1H_NBUF), 0x80000002u);
-		if (PROBE_K1H(p) & 8)
-			return;
-		const uint32_t bo = (K1H_NBUF == 2 && (sn & 1)) ? (uint32_t)(4 * N * 8) : 0u;		/* second buffer: the slot of cluster gc + 4 */
-		/* w[256 q + kk], kk = ia + 16 jj2, at [kk >> 5][q][(kk & 31) ^ 16 (q & 1)]: 16 lanes x 8 B = 128-byte runs; odd residues
-		 * keep their two halves swapped so that one store instruction (one jj for every lane) is spread over both halves of the
-		 * 256-byte rows -- both values of the address bit that picks an L2 channel -- instead of one */
-#pragma unroll
-		for (int jj = 0; jj < 16; jj++) {
-			if (kRpm == 32) bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, bo + 65536u * (jj >> 1));
-			else            bst_v2f<0>(ra[R16_PERM(jj)], rs_w, wst0, bo + 32768u * jj);	/* (one instruction: four residues = 512 B in a row) */
-		}
-	};
-	/* this wave's stores are in the L2: what it has requested SINCE (the IQ of a later spectrum, HBM latency) may stay in flight */
-	auto stores_acked = [&](bool fetched) {
-		if (HALF && fetched) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRpm / (K1H_SPOLL ? NWV : NWV - 1)) : "memory");
-		else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	};
-
-	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
-	fetch_iq(t0, 0);
-	if (1 < p.tile)
-		fetch_iq(t0 + 1, 1);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	wg_barrier_lds();
-	stage_a1(t0, 0);
-	stage_a1x();
-	wg_barrier_lds();				/* every wave has its rows out of buffer 0 */
-	stage_a2();
-	store_a(done);
-	if (2 < p.tile)
-		fetch_iq(t0 + 2, 0);
-	stores_acked(2 < p.tile);
-	arrive(c_a);
-
-#pragma unroll 1
-	for (int u = 0; u < p.tile; u++) {
-		const int t = t0 + u;
-		const bool more = (u + 1 < p.tile);
-
-		K1H_STAMP(0);		/* loop overhead, tile claim (first spectrum of a tile) */
-		poll(c_a, kArr * (done + 1), 0x80000003u);		/* every wave of the cluster has stored its part of this spectrum */
-		K1H_STAMP(1);		/* "spectrum stored?" */
-
-		/* ================= stage B: offsets kk = kRpm member .. ================= */
-		v2f r[16];
-		if (!(PROBE_K1H(p) & 8)) {
-			const uint32_t bo = (K1H_NBUF == 2 && (done & 1)) ? (uint32_t)(4 * N * 8) : 0u;
-			/* residues q = ib + 16 j3 (q & 1 = ib & 1); sc1: the loads miss the CU's L1 by construction and are served by the L2 */
-#pragma unroll
-			for (int jo = 0; jo < 16; jo++)
-				r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, bo + (uint32_t)(2048 * kRpm) * member + (uint32_t)(128 * kRpm) * K1H_PAIR(jo));
-		} else {
-#pragma unroll
-			for (int j = 0; j < 16; j++)
-				r[j] = ra[j];
-		}
-		K1H_STAMP(2);		/* loads of the intermediate issued */
-		if (more) {						/* (while the loads travel: all of the next spectrum's stage A) */
-			stage_a1(t + 1, (u + 1) & 1);
-			stage_a1x();
-			stage_a2();
-		}
-		K1H_STAMP(3);		/* stage A of the next spectrum */
-		pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
-#if K1H_TIMING
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-		K1H_STAMP(4);		/* third pass, stages A and B: includes the wait for the loads */
-		pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
-		arrive(c_b);						/* this wave's loads of the intermediate have landed */
-		K1H_STAMP(5);		/* third pass, stages C and D */
-		wg_barrier_lds();					/* B1 */
-		K1H_STAMP(6);		/* barrier B1 */
-		if (more)
-			store_a(done + 1);
-		/* spectrum u + 3 is requested into the buffer spectrum u + 1 has been read out of by every wave (B1); requested BEHIND the stores
-		 * (their acknowledgements are waited for below, this is not) and behind the loads of the intermediate (loads return in order,
-		 * and these come from HBM); landed and visible at B3 of the next iteration */
-		if (u + 3 < p.tile)
-			fetch_iq(t + 3, (u + 1) & 1);
-		K1H_STAMP(7);		/* "buffer free?" + stores of the next spectrum's stage A + IQ request */
-#pragma unroll
-		for (int jj = 0; jj < 16; jj++)
-			xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
-		K1H_STAMP(8);		/* exchange stores */
-		wg_barrier_lds();					/* B2 */
-		K1H_STAMP(9);		/* exchange barrier B2 */
-#pragma unroll
-		for (int jo = 0; jo < 16; jo++)
-			r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
-		pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
-		pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
-		K1H_STAMP(10);		/* exchange loads + fourth pass */
-		if (more) {
-			stores_acked(u + 3 < p.tile);
-			arrive(c_a);
-		}
-		done++;
-		K1H_STAMP(11);		/* stores acknowledged + arrival */
-		wg_barrier_lds();					/* B3 */
-		K1H_STAMP(12);		/* barrier B3 */
-		epilogue(r, t, u);
-		K1H_STAMP(13);		/* epilogue */
-	}
-#else
 	/* the tile's first spectrum: nothing to hide its stage A behind.  Input buffers: spectrum u of the tile in buffer u & 1 */
 	fetch_iq(t0, 0);
 	if (1 < p.tile)
@@ -2499,7 +2357,6 @@ void k1h_fused(const K1Params p)
 		epilogue(r, t, u);
 		K1H_STAMP(13);		/* epilogue */
 	}
-#endif
 	if (!(PROBE_K1H(p) & 4)) {
 		const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
 #pragma unroll
@@ -2551,7 +2408,7 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 	/* tiles of 4 .. 32 spectra (whole quads of low bytes, the 9th bits of a tile in one dword); tile index: 20 bits of the claim word */
 	if (!p0.sync || !p0.scratch || p0.tile < 4 || p0.tile > 32 || (p0.tile & 3) || p0.total % p0.tile || p0.total / p0.tile >= (1 << 20))
 		return hipErrorInvalidValue;
-	return p0.k1h_waves == 8 ? launch_k1h_form<8>(p0, s) : launch_k1h_form<4>(p0, s);
+	return launch_k1h_form<8>(p0, s);
 }
 
 
@@ -2561,7 +2418,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		return launch_k1h(p, s);
 	const int tiles = p.total / p.tile;
 	if (p.variant == 3) {
-		static bool attr_set = false;
+		static unsigned long long attr_dev = 0;		/* (the attribute belongs to the function object of the CURRENT device: once per device) */
 		if (p.log2n == 10) {
 			/* N = 1024 with 16-bit bin indices (more than 256 bins): the general kernel at 128 threads per spectrum */
 			constexpr int N = 1024;
@@ -2579,13 +2436,16 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 		constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
 		typedef void (*k1w_fn)(const K1Params);
 		static const k1w_fn fns[5] = { k1w_fft_bin<8>, k1w_fft_bin<4>, k1w_fft_bin<2>, k1w_fft_bin<1>, k1w_fft_bin<16> };
-		if (!attr_set) {
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+			return hipErrorInvalidDevice;
+		if (!(attr_dev >> dev & 1)) {
 			for (int i = 0; i < 5; i++) {
 				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw);
 				if (e != hipSuccess)
 					return e;
 			}
-			attr_set = true;
+			attr_dev |= 1ull << dev;
 		}
 		/* rows of 512 samples the next window of a tile shares with this one: hop = 8192 / R, R = 2, 4, 8, 16; any other hop: none */
 		const int which = (p.hop == 4096) ? 0 : (p.hop == 2048) ? 1 : (p.hop == 1024) ? 2 : (p.hop == 512) ? 3 : 4;

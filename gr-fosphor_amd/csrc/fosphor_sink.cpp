@@ -415,8 +415,11 @@ void sink_runtime::worker()						/* :77-122 */
 		render();
 	while (fosphor_amd_pending_uploads(d_fosphor) > 0) {			/* the kernels of the last uploads */
 		int plen = 0;
-		if (fosphor_amd_process_uploaded(d_fosphor, &plen) == 0)
+		const int rv = fosphor_amd_process_uploaded(d_fosphor, &plen);
+		if (rv == 0)
 			d_samples += (uint64_t)plen;
+		else
+			count_dropped(plen, "kernels of an uploaded region", rv);
 	}
 	(void)fosphor_amd_finish(d_fosphor);
 	retire_uploads(true);
@@ -424,6 +427,17 @@ void sink_runtime::worker()						/* :77-122 */
 		std::lock_guard<std::mutex> lk(d_render_mutex);	/* no click is being mapped through it */
 		fosphor_release(d_fosphor);
 		d_fosphor = nullptr;
+	}
+}
+
+/* A region taken from the FIFO and given back unprocessed (the reference ignores fosphor_process's code, base_sink_c_impl.cc:170): counted,
+ * and said once, so that a failing device does not pass for a quiet one -- whichever step failed. */
+void sink_runtime::count_dropped(int len, const char *what, int rv)
+{
+	d_dropped += (uint64_t)(len > 0 ? len : 0);
+	if (!d_drop_reported) {
+		fprintf(stderr, "[!] fosphor_amd sink: %s failed (%d); samples are being dropped\n", what, rv);
+		d_drop_reported = true;
 	}
 }
 
@@ -439,8 +453,11 @@ void sink_runtime::render()						/* :130-201 */
 	 * synchronisation point at the end of a pass then waits for kernels only and the link works on across it) */
 	while (fosphor_amd_pending_uploads(d_fosphor) > 0) {
 		int plen = 0;
-		if (fosphor_amd_process_uploaded(d_fosphor, &plen) == 0)
+		const int rv = fosphor_amd_process_uploaded(d_fosphor, &plen);
+		if (rv == 0)
 			d_samples += (uint64_t)plen;
+		else
+			count_dropped(plen, "kernels of an uploaded region", rv);	/* (uploaded, then not processed: dropped all the same) */
 		queued++;
 	}
 	for (i = 0; i < max_iter; i++) {
@@ -471,15 +488,8 @@ void sink_runtime::render()						/* :130-201 */
 				rv = fosphor_amd_upload_pinned(d_fosphor, data, len);
 				if (rv == -EBUSY)
 					break;				/* both staging buffers hold uploads: their kernels come first (next pass) */
-				if (rv) {
-					/* the region is given back unprocessed (the reference ignores fosphor_process's code, :170): counted, and
-					 * said once, so that a failing device does not pass for a quiet one */
-					d_dropped += (uint64_t)len;
-					if (!d_drop_reported) {
-						fprintf(stderr, "[!] fosphor_amd sink: upload failed (%d); samples are being dropped\n", rv);
-						d_drop_reported = true;
-					}
-				}
+				if (rv)
+					count_dropped(len, "upload", rv);
 				if (!d_events[slot]) {
 					hipEvent_t e;
 					if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess)
@@ -494,7 +504,7 @@ void sink_runtime::render()						/* :130-201 */
 				if (rv == 0)
 					d_samples += (uint64_t)len;
 				else
-					d_dropped += (uint64_t)len;
+					count_dropped(len, "fosphor_process", rv);
 			}
 		}
 		d_inflight[slot].event = ev;

@@ -268,12 +268,14 @@ int fosphor_amd_tune_placement(struct fosphor *self, const void *d_samples, int 
 /* Host-logic test hook (no device needed): batches per sub-launch of a fosphor_amd_process_device* call of n_batches batches of
  * `batch` spectra at FFT length 2^fft_len_log, for a sub-launch size of sub_samples samples (64 Mi by default, 1 Gi at
  * fft_len_log = 13) -- at fft_len_log = 13 with the streams on, whole multiples of the unit that lets a piece share the chip
- * (224 tiles of 64 spectra).  -EINVAL for nonsense. */
+ * (224 tiles of 64 spectra: the split of a 256-CU device; advisory on any other, where no launch shares and the unit only shapes the
+ * pieces).  -EINVAL for nonsense. */
 int fosphor_amd_plan_piece_batches(int fft_len_log, int overlap, int n_batches, int batch, long long sub_samples);
 
-/* fft_len_log = 13 only (zeros otherwise): FFT launches made in the space-sharing form (*cus work-groups, the count / merge kernels of
- * the launch before on the CUs they leave) and in the full-chip form since the instance was made.  *cus = 0: this device never shares
- * (its CU count is not the 256 the split is laid out for).  Which form a launch takes depends on what is still queued when it is
+/* FFT launches made in the space-sharing form (*cus work-groups, the count / merge kernels of the launch before on the CUs they
+ * leave) and in the full-chip form since the instance was made: counted at fft_len_log = 13 only (the one length that shares; both
+ * counters stay 0 otherwise).  *cus is the device's share whatever the length: 224 on a 256-CU device, 0 on any other (this device
+ * never shares: the split is laid out for 256 CUs).  Which form a launch takes depends on what is still queued when it is
  * submitted, never on the data; results are identical (tests: test_c3_space_sharing_*).  Any pointer may be NULL. */
 int fosphor_amd_share_stats(struct fosphor *self, long long *shared, long long *full, int *cus);
 

@@ -150,6 +150,7 @@ class sink_runtime
 	void worker();
 	void render();
 	void retire_uploads(bool wait_all);
+	void count_dropped(int len, const char *what, int rv);
 	void copy_helper(int idx);
 	void settings_mark_changed(uint32_t s) { d_pending.fetch_or(s, std::memory_order_acq_rel); }		/* base_sink_c_impl.cc:204-209 */
 	uint32_t settings_get_and_reset_changed() { return d_pending.exchange(0, std::memory_order_acq_rel); }	/* :211-218 */

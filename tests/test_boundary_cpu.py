@@ -186,6 +186,9 @@ def test_k1w_hand_issued_requests_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_k1w_loads.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("untouched until the wait") == 5, r.stdout		# overlap 2, 4, 8, 16 and the general form
+    # ... the counted wait's immediate equals the index stores an odd spectrum's epilogue issues behind the requests, and nothing spills
+    # inside the spectrum loop's product path (the kernel sits at 256 registers; ScratchSize is printed, budget 64 bytes)
+    assert r.stdout.count("vmcnt(16) = 16 index stores per wave") == 5 and r.stdout.count("no spill in the loop's product path") == 5, r.stdout
 
 
 def test_product_never_touches_the_oracle():
@@ -285,3 +288,23 @@ def test_bench_self_launch_is_a_child_process_and_relays_failure():
     assert "torch.distributed.run" in p.stderr and "--nproc-per-node 2" in p.stderr, p.stderr[-2000:]
     assert p.returncode != 0, "no GPU here: the launched ranks cannot have succeeded"
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_scaling_record_without_the_native_exchange():
+    """bench.py on N > 1 ranks: a line whose exchange was not the native RCCL transport spanning all N ranks (ncclCommCount on every
+    rank) is not a scaling record -- the run is marked `invalid` and exits 3 instead of reporting a rate the driver would divide by
+    N (no silent fallback).  The guard as a pure function; the gloo-on-one-GPU tests pass the hook that says the fallback is meant."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    native = "native RCCL (library communicator)"
+    g = bench.scaling_record_guard
+    assert g(1, "none", [1]) is None						# one rank: nothing to guard
+    assert g(8, native, [8] * 8) is None
+    assert g(2, native, [2, 2]) is None
+    assert "not the native RCCL transport" in g(8, "torch.distributed (nccl)", [8] * 8)
+    assert "not the native RCCL transport" in g(2, "none", [1, 1])
+    assert "not 8 on every rank" in g(8, native, [8, 8, 8, 1, 8, 8, 8, 8])		# one rank's communicator is short
+    assert "not 8 on every rank" in g(8, native, [8] * 7)				# a rank did not report
+    assert "not 2 on every rank" in g(2, native, [1, 1])
+    assert g(2, "torch.distributed (gloo)", [2, 2], test_hook=True) is None		# tests/test_gpu_dist.py: meant

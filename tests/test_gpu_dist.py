@@ -1,5 +1,6 @@
-"""GPU: gr_fosphor_amd.dist.ShardedFosphor -- two ranks on ONE device over gloo, and the native RCCL exchange
-(fosphor_amd_exchange: one ncclGroup on the library's stream) on a single rank.
+"""GPU: gr_fosphor_amd.dist.ShardedFosphor -- two ranks on ONE device over gloo, the native RCCL exchange
+(fosphor_amd_exchange: one ncclGroup on the library's stream) on a single rank, and -- where two devices are visible --
+between two real devices (test_native_rccl_two_real_devices; skipped on the pool's one-GPU boxes).
 
 The 8-GPU RCCL run is the driver's; this exercises the same rank code (time-sharded accumulate,
 per-frame all-reduce of hit counts / live sum / max with the previous frame's exchange left in
@@ -138,6 +139,88 @@ def test_native_rccl_exchange_single_rank(tmp_path, sliced):
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=300)
     assert p.returncode == 0 and "native ok" in p.stdout, p.stdout[-3000:]
+
+
+NATIVE2 = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["FOSPHOR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FOSPHOR_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from _pkg import gr_fosphor_amd
+from gr_fosphor_amd.dist import ShardedFosphor, shard_range
+from oracle_lib import Oracle, gaussian_iq, add_tone, digest
+
+# TWO REAL DEVICES, one process each, the library's own RCCL communicator over xGMI: gloo only carries rank 0's 128-byte id and the
+# digests compared at the end.
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+N = 1024
+sliced = os.environ.get("FOSPHOR_TEST_SLICED") == "1"
+frames = [2048, 1024, 4096, 2048]
+sf = ShardedFosphor(gr_fosphor_amd.Fosphor, rank, world, exchange="rccl", sliced=sliced, max_spectra=4096)
+assert sf.comm is not None and sf.sliced == sliced
+assert sf.exchange_ranks() == world, "ncclCommCount says %d ranks" % sf.exchange_ranks()
+o = Oracle()
+t0 = 0
+keep = []
+for k, total in enumerate(frames):
+    x = add_tone(gaussian_iq(total * N, 270 + k), 0.1, 0.07 + 0.02 * k, t0=t0)
+    t0 += total * N
+    off, n = shard_range(total, rank, world)
+    keep.append(torch.from_numpy(x[off * N:(off + n) * N]).cuda())
+    sf.frame(keep[-1], total)				# accumulate -> exchange -> merge: three asynchronous C calls
+    assert o.process(x, strict=False, nthreads=4) == 0
+sf.gather_state()
+f = sf.f
+assert f.finish() >= 0
+assert f.waterfall_pos == o.waterfall_pos
+assert np.array_equal(f.hitcount, o.hitcount.T), "rank %d: hit counts differ from the oracle" % rank
+h, s = f.histogram, f.spectrum
+assert np.allclose(h, o.histogram, rtol=1e-4, atol=2e-6), "rank %d histogram" % rank
+assert np.allclose(s[..., 1], o.spectrum[..., 1], rtol=1e-4, atol=1e-6), "rank %d spectrum" % rank
+mine = torch.tensor([int(digest(h)[:15], 16), int(digest(s)[:15], 16), int(digest(f.hitcount)[:15], 16)], dtype=torch.int64)
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(b, both[0]) for b in both), "replicated state differs between the ranks"
+off, n = shard_range(frames[-1], rank, world)		# the waterfall rows this rank computed
+rows = (o.waterfall_pos - frames[-1] + off + np.arange(n)) & 1023
+assert np.allclose(f.waterfall[rows], o.waterfall[rows], rtol=1e-4, atol=1e-6)
+dist.barrier()
+sf.close()
+dist.destroy_process_group()
+print("rank %d ok" % rank)
+'''
+
+
+@pytest.mark.parametrize("sliced", ["0", "1"])
+def test_native_rccl_two_real_devices(tmp_path, sliced):
+    """The native RCCL exchange between TWO REAL DEVICES (SURVEY 8e; north_star: per-display-frame RCCL all-reduce over xGMI), both
+    forms -- one ncclGroup of three all-reduces, and reduce-scatter + frequency-sliced merge + all-gather -- with the assertions of
+    the gloo test on the real transport: hit counts array_equal to the oracle's on every rank, histogram / spectrum in tolerance,
+    the replicated state bit-identical across the ranks, ncclCommCount == 2.  Skipped (reason printed) where fewer than two
+    devices are visible: the pool's boxes have one, so the first machine with two runs it."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices for a real 2-rank RCCL exchange; this box shows %d" % torch.cuda.device_count())
+    script = tmp_path / "native2.py"
+    script.write_text(NATIVE2)
+    env = dict(os.environ, FOSPHOR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", WORLD_SIZE="2", FOSPHOR_TEST_SLICED=sliced)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+        assert "rank %d ok" % r in out
 
 
 def test_c_program_native_exchange(tmp_path):

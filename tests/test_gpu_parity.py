@@ -1330,14 +1330,11 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overl
     f.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "8"])
-def test_fft65536_bit_exact(amd, torch_cuda, oracle_built, monkeypatch, waves):
+def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
     """N = 65536 in two 256-point levels (passes p = 1, 16 per residue mod 256 inside a wavefront; passes p = 256, 4096 per
     offset mod 256 in a work-group; the spectrum between them in the XCD's L2): the bits of the oracle's radix-16 plan of FMA butterflies
-    (this build's own plan at this length: no reference behaviour exists), fp32 and fp16 input.  Both forms of the kernel: work-groups
-    of 4 waves (two per CU, clusters of 16: the default) and of 8 (one per CU, clusters of 8)."""
+    (this build's own plan at this length: no reference behaviour exists), fp32 and fp16 input."""
     torch = torch_cuda
-    monkeypatch.setenv("FOSPHOR_AMD_K1H_WAVES", waves)
     n = 65536
     o = Oracle(fft_len_log=16, n_bins=512, wf_rows=64)
     x = gaussian_iq(8 * n, 90, sigma=1.0).reshape(8, n, 2)
@@ -1637,10 +1634,9 @@ def _c5_outputs(f):
     return [canon_bits(f.waterfall), canon_bits(f.histogram), canon_bits(f.spectrum), f.hitcount.copy()]
 
 
-@pytest.mark.parametrize("tile", [None, "4", "16", "nomask", "waves8", "waves8-4"])
+@pytest.mark.parametrize("tile", [None, "4", "16", "nomask"])
 def test_c5_call_shapes_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, tile):
-    """N = 65536 (fp16 IQ, 512 bins) through the fused two-level kernel (clusters of 16 -- or, FOSPHOR_AMD_K1H_WAVES=8, of 8 --
-    work-groups per XCD, the intermediate
+    """N = 65536 (fp16 IQ, 512 bins) through the fused two-level kernel (clusters of 8 work-groups per XCD, the intermediate
     spectrum resident in the XCD's L2) over calls whose tile counts do not divide evenly among the clusters, multi-batch calls
     and a ring wrap, with the tile lengths small launches pick and forced ones (the 9th-bit plane of the bin indices is laid
     out per tile), sparse and dense count hand-off: every call against the oracle."""
@@ -1649,10 +1645,6 @@ def test_c5_call_shapes_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, ti
     threads = min(os.cpu_count() or 1, 64)
     monkeypatch.delenv("FOSPHOR_AMD_TILE", raising=False)
     monkeypatch.delenv("FOSPHOR_AMD_ROWMASK", raising=False)
-    monkeypatch.delenv("FOSPHOR_AMD_K1H_WAVES", raising=False)
-    if tile and tile.startswith("waves8"):
-        monkeypatch.setenv("FOSPHOR_AMD_K1H_WAVES", "8")
-        tile = tile[7:] or None
     if tile == "nomask":
         tile = None
         monkeypatch.setenv("FOSPHOR_AMD_ROWMASK", "0")

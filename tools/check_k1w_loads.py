@@ -86,7 +86,40 @@ def check(path):
             for i, l in bad[:10]:
                 print("%s +%d: %s" % (name, i, l), file=sys.stderr)
             raise SystemExit("%s: %d instruction(s) touch an in-flight IQ register between its request and the wait" % (name, len(bad)))
-        report.append("%s: %d requests -> v%d..v%d, untouched until the wait (loop %s, %d lines)" % (name, len(loads), min(dests), max(dests), label, tail - header))
+        # The counted wait's immediate must equal what an ODD spectrum's epilogue issues BEHIND the requests: its index stores (inline
+        # assembly `global_store_dword`, one copy of the three pieces for the early and one for the late waves of a SIMD).  A change
+        # that packs the stores must change the immediate with them (kK1wIdxStores), or the wait returns before the IQ has landed.
+        imm = int(re.search(r"vmcnt\((\d+)\)", body[w]).group(1))
+        idx_stores, in_asm = 0, False
+        for i in range(header, tail + 1):
+            l = body[i]
+            if "ASMSTART" in l:
+                in_asm = True
+            elif "ASMEND" in l:
+                in_asm = False
+            elif in_asm and re.match(r"\s*global_store_dword\s", l):
+                idx_stores += 1
+        if idx_stores != 2 * imm:
+            raise SystemExit("%s: the counted wait is vmcnt(%d) but the loop holds %d hand-issued index stores (expected 2 x %d: early and late copy)"
+                             % (name, imm, idx_stores, imm))
+        # Spills: none inside the spectrum loop but for the fft_out test hook's block (the one with the global_store_dwordx2 of the
+        # spectrum itself); the kernel sits at 256 registers, so a compiler bump could move one into the hot path unnoticed.
+        blocks, cur = [], []
+        for i in range(header, tail + 1):
+            if re.match(r"^\.LBB\d+_\d+:", body[i]) and cur:
+                blocks.append(cur)
+                cur = []
+            cur.append(body[i])
+        blocks.append(cur)
+        hot_spills = sum(1 for b in blocks if any("scratch_" in l for l in b) and not any("global_store_dwordx2" in l for l in b))
+        if hot_spills:
+            raise SystemExit("%s: %d basic block(s) of the spectrum loop spill or reload outside the fft_out test path" % (name, hot_spills))
+        scratch = next((int(m.group(1)) for l in src[st:end + 200] for m in [re.search(r";\s*ScratchSize:\s*(\d+)", l)] if m), -1)
+        if scratch > 64:
+            raise SystemExit("%s: ScratchSize %d bytes per lane (budget: 64, all of it outside the spectrum loop)" % (name, scratch))
+        report.append("%s: %d requests -> v%d..v%d, untouched until the wait (loop %s, %d lines); vmcnt(%d) = %d index stores per wave; "
+                      "no spill in the loop's product path; ScratchSize %d"
+                      % (name, len(loads), min(dests), max(dests), label, tail - header, imm, idx_stores // 2, scratch))
     return report
 
 
