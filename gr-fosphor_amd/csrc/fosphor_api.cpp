@@ -821,7 +821,7 @@ error:
 static int pick_tile(const struct fosphor *self, int total, int batch)
 {
 	const int v = self->kn_tile;
-	if (v >= 4 && v <= (self->log2n == 16 ? 32 : 128) && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
+	if (v >= (self->log2n == 13 ? 8 : 4) && v <= (self->log2n == 16 ? 32 : 128) && !(v & (v - 1)) && batch % v == 0 && total % v == 0)
 		return v;
 	if (self->log2n == 16 && self->k1h_fused) {
 		/* a cluster owns whole tiles: the largest tile that still gives each of the 32 clusters one (at most 32 spectra: the
@@ -838,7 +838,7 @@ static int pick_tile(const struct fosphor *self, int total, int batch)
 		for (int t = 64; t >= 8; t >>= 1)
 			if (batch % t == 0 && total / t >= 256)
 				return t;
-		return 4;
+		return 8;		/* (at least 8: the 9th bits of a tile's bin indices go out as one byte per column and eight spectra) */
 	}
 	if (self->log2n != 10 || self->bins16) {
 		/* largest tile that still gives every resident wave (256 CUs x 8) a tile */
@@ -987,7 +987,7 @@ static int run_count(struct fosphor *self, int n_batches, int batch, int tile, i
 	if (sum16)
 		k2.hc16 = self->d_slab16, k2.rowmask = NULL;
 	const int lslot = slot0 + hset * self->max_batches;	/* live-sum / max slot */
-	k2.n = self->n; k2.bins16 = self->bins16;
+	k2.n = self->n; k2.bins16 = self->bins16 && self->log2n != 13; k2.bins8p1 = (self->log2n == 13);
 	k2.bins9 = (self->log2n == 16); k2.total = n_batches * batch;
 	k2.batch = batch; k2.chunk = chunk; k2.tile = tile; k2.n_bins = self->n_bins;
 	k2.w = 1.0f - self->alpha;
@@ -1589,7 +1589,10 @@ extern "C" int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_o
 	if (prepare(self)) { self->state = saved_state; return -EIO; }
 	self->state = saved_state;
 	/* rows are not stored (wf_first = total); bins/partials land in scratch */
-	fill_k1(self, &k1, d_in, n_spectra, 4, 0, n_spectra);
+	/* (N = 8192: tiles of at least 8 spectra -- the 9th bits of the bin indices go out per eight spectra) */
+	if (self->log2n == 13 && (n_spectra & 7))
+		return -EINVAL;
+	fill_k1(self, &k1, d_in, n_spectra, self->log2n == 13 ? 8 : 4, 0, n_spectra);
 	k1.fft_out = (float2 *)d_out;
 	if (launch_k1(k1, self->stream) != hipSuccess)
 		return -EIO;
@@ -1708,7 +1711,7 @@ static int accumulate(struct fosphor *self, const void *d_samples, int n_local, 
 				k2.bins = self->d_bins; k2.partial = self->d_partial;
 				k2.hc = self->d_hc + (size_t)self->slot * cells;
 				k2.hc16 = self->d_slab16 + (size_t)(c0 / G) * cells;
-				k2.n = self->n; k2.bins16 = self->bins16;
+				k2.n = self->n; k2.bins16 = self->bins16 && self->log2n != 13; k2.bins8p1 = (self->log2n == 13);
 				k2.bins9 = (self->log2n == 16); k2.total = sub_total;
 				k2.batch = sub_total; k2.chunk = 1024 * G; k2.tile = tile; k2.n_bins = self->n_bins;
 				k2.w = 1.0f - self->alpha;

@@ -80,6 +80,8 @@ struct K2Params {
 	float    *chunk_max;		/* [n_chunks][N] */
 	int   n;			/* FFT length (columns) */
 	int   bins16;			/* bin indices are 16-bit, 2 spectra per dword */
+	int   bins8p1;			/* N = 8192: shorts [total / 2][N] (the low bytes of two spectra), then bytes [total / 8][N] (bit u = the 9th bit
+					 * of the group's spectrum u): 1.125 B per sample; chunks are multiples of 8 spectra */
 	int   bins9;			/* N = 65536: low bytes as [total / 4][N] dwords (4 spectra per dword), then the 9th bits as
 					 * [total / tile][N] dwords (bit u = spectrum u of the tile) */
 	int   total;			/* spectra of the FFT launch that wrote `bins` (locates the 9th-bit plane) */

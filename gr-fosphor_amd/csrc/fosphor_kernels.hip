@@ -1425,6 +1425,8 @@ void k1w_fft_bin(const K1Params p)
 
 	/* ---- per-thread constants ------------------------------------------------ */
 	const int hh = th >> 8, kk = th & 255;		/* item th = kk + 256 hh of the pass p = 256 */
+	const int hu = __builtin_amdgcn_readfirstlane(th >> 8);	/* = hh, as a scalar (wave-uniform: waves 0-3 / 4-7), for the whole kernel: taken inside the spectrum
+								 * loop it kept th >> 8 alive in a vector register -- the one the general-hop form spilled */
 	const v2f w16c = twg[p.tw_off[0]], w8c = twg[p.tw_off[0] + 1], w163c = twg[p.tw_off[0] + 2];	/* W16, W8, W16^3: the first pass */
 	v2f wab[8];			/* taps of elements th + 512 j and th + 512 (j + 8): the pair of a first-pass stage-A butterfly */
 	v2f tw16[8], tw256[8];		/* w^8, w^4, w^2, w^2 W8, w, w W16, w W8, w W16^3 for k = th & 15, th & 255 */
@@ -1460,8 +1462,11 @@ void k1w_fft_bin(const K1Params p)
 	};
 
 	v2f q[16];			/* raw IQ of the spectrum to be processed next: rows th + 512 j */
-	uint16_t *bins16 = reinterpret_cast<uint16_t *>(p.bins);
-	const uint32_t cb = (uint32_t)kk + 2048u * (uint32_t)hh;	/* column of xo[m]: cb + 256 (m & 7) + 4096 (m >> 3) */
+	/* column of xo[m]: cb + 256 (m & 7) + 4096 (m >> 3), cb = kk + 2048 hh.  ONE register carries it through the spectrum loop, as the
+	 * byte offset 2 cb of the column's short in an index row (the kernel has no register to spare: tools/check_k1w_loads.py); the rare
+	 * users of cb itself (waterfall rows, the bytes of 9th bits, the tile's partials) take it back out of it where they run */
+	const uint32_t cb2 = 2u * ((uint32_t)kk + 2048u * (uint32_t)hh);
+#define K1W_CB() ({ uint32_t _c; asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(_c) : "v"(cb2)); _c; })
 
 	/* Epilogue of columns [M0, M1) of spectrum tp, whose FFT is in xo: log-power, exact 16-bit bin, live / max, waterfall row
 	 * (display.cl:136-150,161-168).  Per column, nothing carried from column to column: it is cut into three pieces that
@@ -1476,14 +1481,20 @@ void k1w_fft_bin(const K1Params p)
 		if (K1W_P(4)) break; \
 		if (K1W_PRIO) __builtin_amdgcn_s_setprio(0); \
 		const bool _row = ((tp) >= p.wf_first); \
-		float *_wf = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N + cb; \
-		/* index stores: one dword per column and PAIR of spectra (the layout the count kernel reads: 16-bit indices, two spectra per dword). \
-		 * A vector-memory instruction costs a CU 11-17 cycles whatever it carries (tools/ubench/vmem_rate.hip: 16.5 for 64 strided shorts, \
-		 * 10.8 for 64 dwords), and with a 16-bit store per sample the index stores were a quarter of this kernel's time: the indices of an \
-		 * even spectrum wait in eight registers for the odd one's (tiles are even: launch_k1).  Scalar base (SALU) + ONE lane offset + \
-		 * immediate; byte offset of column cb + K1W_COL(m) in the row: 4 cb + 1024 (m & 7) + 16384 (m >> 3) */ \
-		const char *_bdu = reinterpret_cast<const char *>(bins16 + (size_t)((tp) >> 1) * N * 2); \
-		const uint32_t _bo = 4u * cb; \
+		float *_wfr = p.wf + (size_t)((p.wf_pos0 + (tp)) & p.wf_mask) * N; \
+		/* index stores (512 bins: 9 bits), 1.125 B per sample instead of the 2 B of a 16-bit index (round 6): \
+		 *   low bytes   one SHORT per column and PAIR of spectra, [t / 2][column] (even spectrum in the low byte) \
+		 *   9th bits    one BYTE per column and EIGHT spectra, [t / 8][column] behind the shorts (bit u = spectrum 8 (t / 8) + u) \
+		 * A vector-memory instruction costs a CU 8-17 cycles whatever it carries (tools/ubench/vmem_rate.hip: 8.2 for 64 dense shorts, \
+		 * 10.8 for 64 dwords), and with a store per sample the index stores were a quarter of this kernel's time: the low bytes of an \
+		 * even spectrum wait in four registers (four columns each) for the odd one's, the 9th bits of eight spectra in four more \
+		 * (tiles are multiples of 8: launch_k1).  Scalar base (SALU) + ONE lane offset + immediate; column cb + K1W_COL(m) of a row: \
+		 * shorts at 2 cb + 512 (m & 7) + 8192 (m >> 3), bytes at cb + 256 (m & 7) + 4096 (m >> 3) */ \
+		const char *_blo = reinterpret_cast<const char *>(p.bins) + (size_t)((tp) >> 1) * (N * 2); \
+		const char *_bhi = reinterpret_cast<const char *>(p.bins) + (size_t)p.total * N + (size_t)((tp) >> 3) * N; \
+		const uint32_t _bo2 = cb2; \
+		const uint32_t _sh = (uint32_t)(tp) & 7u;		/* uniform */ \
+		if ((M0) == 0 && _sh == 0) { hi9[0] = 0; hi9[1] = 0; hi9[2] = 0; hi9[3] = 0; } \
 		float _l2[(M1) - (M0)]; uint32_t _bn[(M1) - (M0)]; uint32_t _amb = 0; \
 		_Pragma("unroll") \
 		for (int m = (M0); m < (M1); m++) { \
@@ -1506,20 +1517,52 @@ void k1w_fft_bin(const K1Params p)
 				} \
 			} \
 		} \
-		if (!((tp) & 1)) {		/* (uniform: ONE branch per piece) even spectrum: keep the indices, two columns per register */ \
+		_Pragma("unroll") \
+		for (int m = (M0); m < (M1); m++)		/* the 9th bit joins its column's byte: bit (t & 7) */ \
+			hi9[m >> 2] = (__builtin_amdgcn_ubfe(_bn[m - (M0)], 8, 1) << (8 * (m & 3) + _sh)) | hi9[m >> 2]; \
+		if (!((tp) & 1)) {		/* (uniform: ONE branch per piece) even spectrum: keep the low bytes, four columns per register */ \
 			_Pragma("unroll") \
 			for (int m = (M0); m < (M1); m++) \
-				held[m >> 1] = (m & 1) ? __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 1], 0x05040100u) : _bn[m - (M0)]; \
-		} else if (!K1W_P(8)) {		/* odd spectrum: the dword of both */ \
+				held[m >> 2] = __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 2], \
+				                                     (m & 3) == 0 ? 0x03020104u : (m & 3) == 1 ? 0x03020400u : (m & 3) == 2 ? 0x03040100u : 0x04020100u); \
+		} else if (!K1W_P(8)) {		/* odd spectrum: the short of both */ \
 			_Pragma("unroll") \
 			for (int m = (M0); m < (M1); m++) { \
-				const char *_sb = _bdu + 4096 * ((m & 7) >> 2) + 16384 * (m >> 3); \
-				const uint32_t _d = __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 1], (m & 1) ? 0x05040302u : 0x05040100u); \
-				switch (m & 3) { \
-				case 0:  asm volatile("global_store_dword %0, %1, %2" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
-				case 1:  asm volatile("global_store_dword %0, %1, %2 offset:1024" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
-				case 2:  asm volatile("global_store_dword %0, %1, %2 offset:2048" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
-				default: asm volatile("global_store_dword %0, %1, %2 offset:3072" :: "v"(_bo), "v"(_d), "s"(_sb) : "memory"); break; \
+				const char *_sb = _blo + 8192 * (m >> 3); \
+				const uint32_t _d = __builtin_amdgcn_perm(_bn[m - (M0)], held[m >> 2], 0x0c0c0400u | (uint32_t)(m & 3)); \
+				switch (m & 7) { \
+				case 0:  asm volatile("global_store_short %0, %1, %2" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 1:  asm volatile("global_store_short %0, %1, %2 offset:512" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 2:  asm volatile("global_store_short %0, %1, %2 offset:1024" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 3:  asm volatile("global_store_short %0, %1, %2 offset:1536" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 4:  asm volatile("global_store_short %0, %1, %2 offset:2048" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 5:  asm volatile("global_store_short %0, %1, %2 offset:2560" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				case 6:  asm volatile("global_store_short %0, %1, %2 offset:3072" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				default: asm volatile("global_store_short %0, %1, %2 offset:3584" :: "v"(_bo2), "v"(_d), "s"(_sb) : "memory"); break; \
+				} \
+			} \
+			if (_sh == 7) {		/* (uniform) the eighth spectrum: the bytes of 9th bits, scalar base + one lane offset + immediate like the shorts; \
+						 * byte 0 / 2 of a register as it is (global_store_byte / _d16_hi), byte 1 / 3 of its copy shifted by 8 */ \
+				const uint32_t cb = K1W_CB(); \
+				_Pragma("unroll") \
+				for (int m = (M0); m < (M1); m++) { \
+					const char *_hb = _bhi + 4096 * (m >> 3); \
+					const uint32_t _hv = (m & 1) ? (hi9[m >> 2] >> 8) : hi9[m >> 2]; \
+					if (m & 2) { \
+						switch (m & 7) { \
+						case 2:  asm volatile("global_store_byte_d16_hi %0, %1, %2 offset:512" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						case 3:  asm volatile("global_store_byte_d16_hi %0, %1, %2 offset:768" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						case 6:  asm volatile("global_store_byte_d16_hi %0, %1, %2 offset:1536" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						default: asm volatile("global_store_byte_d16_hi %0, %1, %2 offset:1792" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						} \
+					} else { \
+						switch (m & 7) { \
+						case 0:  asm volatile("global_store_byte %0, %1, %2" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						case 1:  asm volatile("global_store_byte %0, %1, %2 offset:256" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						case 4:  asm volatile("global_store_byte %0, %1, %2 offset:1024" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						default: asm volatile("global_store_byte %0, %1, %2 offset:1280" :: "v"(cb), "v"(_hv), "s"(_hb) : "memory"); break; \
+						} \
+					} \
 				} \
 			} \
 		} \
@@ -1530,6 +1573,7 @@ void k1w_fft_bin(const K1Params p)
 		} \
 		if (_row) {		/* uniform, rare (the last wf_rows spectra of a call): one branch per piece instead of one per sample; the row \
 					 * values are recomputed from the log-powers, which the live / max updates above kept alive anyway */ \
+			float *_wf = _wfr + K1W_CB(); \
 			_Pragma("unroll") \
 			for (int m = (M0); m < (M1); m++) \
 				_wf[K1W_COL(m)] = _l2[m - (M0)] * F_HALF_LOG10_2; \
@@ -1545,7 +1589,8 @@ void k1w_fft_bin(const K1Params p)
 	for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 	const int t0 = tile * p.tile;
 	float live[16], vmax[16];
-	uint32_t held[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };	/* bin indices of the tile's last even spectrum, two columns per register */
+	uint32_t held[4] = { 0, 0, 0, 0 };		/* low bytes of the tile's last even spectrum's bin indices, four columns per register */
+	uint32_t hi9[4] = { 0, 0, 0, 0 };		/* 9th bits of the indices of up to eight spectra, one byte per column, four columns per register */
 #pragma unroll
 	for (int m = 0; m < 16; m++) { live[m] = 0.0f; vmax[m] = vmax_init; }
 
@@ -1566,7 +1611,6 @@ void k1w_fft_bin(const K1Params p)
 		const bool have_prev = g > 0;			/* uniform */
 		/* The two waves of a SIMD (waves w and w + 4 of the work-group) run their epilogue pieces on opposite sides of the barrier:
 		 * one computes while the other waits for its LDS loads, instead of all eight moving from LDS to VALU and back together */
-		const int hu = __builtin_amdgcn_readfirstlane(th >> 8);	/* = hh, as a scalar */
 		const bool late = hu != 0;
 		v2f x[16];
 		{ v2f *sw = slab0; slab0 = slab1; slab1 = sw; }		/* (the first spectrum starts on the second slab) */
@@ -1726,7 +1770,7 @@ void k1w_fft_bin(const K1Params p)
 		if (p.fft_out) {		/* (tests) */
 #pragma unroll
 			for (int m = 0; m < 16; m++)
-				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + cb + K1W_COL(m)] = xo[m];
+				reinterpret_cast<v2f *>(p.fft_out)[(size_t)t * N + K1W_CB() + K1W_COL(m)] = xo[m];
 		}
 	}
 	/* the last iteration's requests (made unconditionally, see above) still own their registers: nothing may reuse them before they have landed */
@@ -1734,7 +1778,7 @@ void k1w_fft_bin(const K1Params p)
 	             "+v"(q[8]), "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]));
 	K1W_EPI(0, 16, t0 + p.tile - 1);		/* the tile's last spectrum */
 
-	float2 *pp2 = p.partial + (size_t)tile * N + cb;
+	float2 *pp2 = p.partial + (size_t)tile * N + K1W_CB();
 #pragma unroll
 	for (int m = 0; m < 16; m++)
 		pp2[K1W_COL(m)] = make_float2(live[m] * F_HALF_LOG10_2,
@@ -1748,6 +1792,7 @@ void k1w_fft_bin(const K1Params p)
 	}
 #endif
 #undef K1W_EPI
+#undef K1W_CB
 #undef K1W_COL
 }
 
@@ -2430,7 +2475,7 @@ hipError_t launch_k1(const K1Params &p, hipStream_t s)
 				hipLaunchKernelGGL((k1big_fft_bin<10, false>), dim3(blocks), dim3(N / 8), lds, s, p);
 			return hipGetLastError();
 		}
-		if (p.log2n != 13 || (p.tile & 1))		/* (the kernel pairs the index rows of spectra 2 u, 2 u + 1 inside a tile) */
+		if (p.log2n != 13 || (p.tile & 7) || (p.total & 7))	/* (the kernel packs the 9th bits of spectra 8 u .. 8 u + 7 of a tile into one byte per column) */
 			return hipErrorInvalidValue;
 		/* N = 8192: 16 points per thread, tables in registers, overlap reuse in registers (k1w_fft_bin); any hop */
 		constexpr int ldsw = 2 * 8192 * 8 + 520 * 8;	/* two slabs + the exact-bin thresholds */
@@ -2619,6 +2664,48 @@ void k2_count(const K2Params p)
 				}
 			}
 		}
+	} else if (p.bins8p1) {
+		/* the 8192-point kernel's indices: shorts [t / 2][column] (low bytes of two spectra) and, behind them, bytes [t / 8][column]
+		 * (the 9th bits of eight).  A wave takes whole groups of eight spectra of its 64 columns: one byte and four shorts per lane,
+		 * two groups' worth requested before the first is used.  Scalar descriptor + one lane offset + scalar row offsets. */
+		const __amdgpu_buffer_rsrc_t rlo = make_rsrc(reinterpret_cast<const char *>(p.bins) + ((size_t)c * (p.chunk >> 1) * p.n + x0) * 2);
+		const __amdgpu_buffer_rsrc_t rhi = make_rsrc(reinterpret_cast<const char *>(p.bins) + (size_t)p.total * p.n + (size_t)c * (p.chunk >> 3) * p.n + x0);
+		const uint32_t noct = (uint32_t)p.chunk >> 3, rowlo = 2u * (uint32_t)p.n, rowhi = (uint32_t)p.n;
+		const uint32_t lane2 = 2u * (uint32_t)lane, hc4 = 4u * (uint32_t)hcol;
+		auto count8 = [&](uint32_t hv, const uint32_t (&v)[4]) {
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				/* bin = low byte | 9th bit << 8; the row of the histogram is bin << 7 (lds_count) */
+				lds_count(h, lo8(v[u]) | ((hv << (8 - 2 * u)) & 0x100u), hc4, inc);
+				lds_count(h, ((v[u] >> 8) & 0xffu) | ((hv << (7 - 2 * u)) & 0x100u), hc4, inc);
+			}
+		};
+		uint32_t o = wv;
+#pragma unroll 1
+		for (; o + NW < noct; o += 2 * NW) {
+			const uint32_t so_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o * 4u * rowlo));
+			const uint32_t so_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o * rowhi));
+			uint32_t va[4], vb[4];
+			const uint32_t ha = __builtin_amdgcn_raw_buffer_load_b8(rhi, (uint32_t)lane, so_h, 0);
+			const uint32_t hb = __builtin_amdgcn_raw_buffer_load_b8(rhi, (uint32_t)lane, so_h + (uint32_t)NW * rowhi, 0);
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				va[u] = __builtin_amdgcn_raw_buffer_load_b16(rlo, lane2, so_l + (uint32_t)u * rowlo, 0);
+				vb[u] = __builtin_amdgcn_raw_buffer_load_b16(rlo, lane2, so_l + (uint32_t)(4 * NW + u) * rowlo, 0);
+			}
+			count8(ha, va);
+			count8(hb, vb);
+		}
+#pragma unroll 1
+		for (; o < noct; o += NW) {
+			const uint32_t so_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(o * 4u * rowlo));
+			uint32_t va[4];
+			const uint32_t ha = __builtin_amdgcn_raw_buffer_load_b8(rhi, (uint32_t)lane, (uint32_t)__builtin_amdgcn_readfirstlane((int)(o * rowhi)), 0);
+#pragma unroll
+			for (int u = 0; u < 4; u++)
+				va[u] = __builtin_amdgcn_raw_buffer_load_b16(rlo, lane2, so_l + (uint32_t)u * rowlo, 0);
+			count8(ha, va);
+		}
 	} else if (p.bins16) {
 		/* scalar descriptor + ONE lane offset + a scalar row offset per load (plain pointers cost a 64-bit per-lane address, two VALU
 		 * operations, per row), and two operations per atomic's address (mask / shift, then shift-and-add onto the lane's column offset;
@@ -2792,7 +2879,7 @@ hipError_t launch_k2(const K2Params &p, int n_chunks, hipStream_t s)
 #ifndef K2_IF16
 #define K2_IF16 4		/* index loads in flight per thread, 16-bit / 9-bit index geometries (A/B builds) */
 #endif
-	if (p.bins16 || p.bins9)
+	if (p.bins16 || p.bins9 || p.bins8p1)
 		hipLaunchKernelGGL((k2_count<16, K2_IF16>), dim3((p.n / 64), n_chunks), dim3(1024), lds, s, p);
 	else if (p.chunk > 1024)
 		hipLaunchKernelGGL((k2_count<4, 4>), dim3((p.n / 64), n_chunks), dim3(256), lds, s, p);

@@ -87,7 +87,7 @@ def check(path):
                 print("%s +%d: %s" % (name, i, l), file=sys.stderr)
             raise SystemExit("%s: %d instruction(s) touch an in-flight IQ register between its request and the wait" % (name, len(bad)))
         # The counted wait's immediate must equal what an ODD spectrum's epilogue issues BEHIND the requests: its index stores (inline
-        # assembly `global_store_dword`, one copy of the three pieces for the early and one for the late waves of a SIMD).  A change
+        # assembly `global_store_short`, one copy of the three pieces for the early and one for the late waves of a SIMD).  A change
         # that packs the stores must change the immediate with them (kK1wIdxStores), or the wait returns before the IQ has landed.
         imm = int(re.search(r"vmcnt\((\d+)\)", body[w]).group(1))
         idx_stores, in_asm = 0, False
@@ -97,7 +97,7 @@ def check(path):
                 in_asm = True
             elif "ASMEND" in l:
                 in_asm = False
-            elif in_asm and re.match(r"\s*global_store_dword\s", l):
+            elif in_asm and re.match(r"\s*global_store_short\s", l):
                 idx_stores += 1
         if idx_stores != 2 * imm:
             raise SystemExit("%s: the counted wait is vmcnt(%d) but the loop holds %d hand-issued index stores (expected 2 x %d: early and late copy)"

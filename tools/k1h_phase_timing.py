@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of the 65536-point kernel's loop from a K1H_TIMING=1 build (probe build, timing only).
+"""Per-phase cycle breakdown of the 65536-point kernel's loop from a K1H_TIMING=1 build (probe build, timing only; with
+-DFOSPHOR_AMD_PROBES as well, FOSPHOR_AMD_DBG_K1H=15 times the loop without memory accesses and cluster waits).
 
     tools/ab_build.sh "k1htime:-DK1H_TIMING=1"
     gpurun -- 'FOSPHOR_AMD_LIB=$PWD/build/ab/lib_k1htime.so FOSPHOR_AMD_K1_TIMING=1 FOSPHOR_AMD_OVERLAP=0 python3 tools/k1h_phase_timing.py'
@@ -23,18 +24,14 @@ for _ in range(4):
     f.finish()
 L = f.L
 L.fosphor_amd_debug_k1_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-waves = 8 if os.environ.get("FOSPHOR_AMD_K1H_WAVES") == "8" else 4
-wgs = 256 * 8 // waves
+waves = 8
+wgs = 256
 out = np.zeros(wgs * 3 * 16, np.int64)
 assert L.fosphor_amd_debug_k1_timing(f.h, out.ctypes.data, out.size) == 0
 t = out.reshape(wgs, 3, 16).astype(np.float64)
-names = ["loop overhead / tile claim", "poll: spectrum stored by every wave?", "loads of the intermediate issued", "stage A of the next spectrum",
-         "pass 3 AB incl. load wait", "pass 3 CD + arrival", "barrier B1", "poll: buffer free? + stores + IQ request", "exchange stores",
-         "barrier B2", "exchange loads + pass 4", "stores acknowledged + arrival", "barrier B3", "epilogue", "-", "-"]
-if os.environ.get("K1H_SCHED") == "1":		# a -DK1H_SCHED=1 -DK1H_TIMING=1 build: the in-line hand-over of rounds 4-5
-    names = ["loop overhead / tile claim", "top barrier", "stores + pass 1 (next)", "wait stores acked (+IQ DMA)", "barrier + arrive",
-             "transpose (+pass 2 part)", "cluster barrier: poll + wg barrier", "loads issued + pass 2 (next)", "pass 3 AB incl. load wait",
-             "IQ request + pass 3 CD + xb stores", "exchange barrier", "xb loads + pass 4", "c_b poll (last wave)", "epilogue", "-", "-"]
+names = ["loop overhead / tile claim", "own look at 'intermediate read by all?'", "stores + pass 1 (next)", "wait stores acked (+IQ DMA)", "barrier + arrive",
+         "transpose (+pass 2 part)", "cluster barrier: poll + wg barrier", "loads issued + pass 2 (next)", "pass 3 AB incl. load wait",
+         "IQ request + pass 3 CD + xb stores", "exchange barrier", "xb loads + pass 4", "-", "epilogue", "-", "-"]
 live = t[:, 0, :].sum(1) > 0		# work-groups whose cluster did work
 spw = total / 32.0			# spectra per cluster (mean)
 print("work-groups of %d waves; with work: %d of %d; s_memtime cycles per spectrum (mean over them), first / middle / last wave:" % (waves, live.sum(), wgs))
