@@ -123,7 +123,6 @@ struct fosphor
 	int       kn_no_sum16;			/* FOSPHOR_AMD_NO_SUM16 */
 	int       kn_frame_group;		/* FOSPHOR_AMD_FRAME_GROUP: chunks per count work-group of a sharded frame (default 4) */
 	int       kn_k1w_share_off;		/* FOSPHOR_AMD_K1W_SHARE=0: no space sharing at N = 8192 */
-	int       kn_k1h_form;			/* FOSPHOR_AMD_K1H_FORM: 65536-point kernel, 0 specialised waves (default), 1 one program for all eight waves */
 	int       n_cus;			/* hipDeviceProp_t::multiProcessorCount */
 	int       share_cus;			/* N = 8192: work-groups of an FFT launch that leaves CUs to the count / merge kernels (0: never) */
 	long long k1w_shared, k1w_full;		/* N = 8192: FFT launches made in the shared / the full-chip form (fosphor_amd_share_stats) */
@@ -492,7 +491,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->kn_no_sum16 = getenv("FOSPHOR_AMD_NO_SUM16") != NULL;
 		e = getenv("FOSPHOR_AMD_FRAME_GROUP"); self->kn_frame_group = e ? atoi(e) : 4;
 		e = getenv("FOSPHOR_AMD_K1W_SHARE");   self->kn_k1w_share_off = (e && *e == '0');
-		e = getenv("FOSPHOR_AMD_K1H_FORM");    self->kn_k1h_form = (e && *e == '1') ? 1 : 0;
 	}
 
 	/* Measurement only, probe builds (-DFOSPHOR_AMD_PROBES; profiles/r04_ceiling.md): FOSPHOR_AMD_DBG_CUMASK=k reserves k CUs (k / 8 per XCD; mask bit i is CU i / 8 of
@@ -905,7 +903,6 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
 	}
 #endif
 	k1->iq_half = self->iq_half;
-	k1->k1h_form = self->kn_k1h_form;
 	k1->n_cus = self->n_cus;
 	{
 		const int sc = self->share_cus;

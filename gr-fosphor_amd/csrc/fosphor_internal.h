@@ -44,7 +44,6 @@ struct K1Params {
 	long long    *dbg;		/* K1_TIMING builds: [waves][8] cycle accumulators, or nullptr */
 	float2       *scratch;		/* variant 4: [64 clusters][N] intermediate spectrum between the two stages */
 	int   iq_half;			/* variant 4: the IQ stream is fp16 (re, im) pairs, 4 B per sample */
-	int   k1h_form;			/* variant 4: 0 specialised waves (k1h_split: 12 waves, producers + consumers), 1 one program for all (k1h_fused, 8 waves) */
 	uint32_t *sync;			/* variant 4: cluster counters [64][64] */
 	uint32_t *sync_err;		/* ... its error word (host-mapped): set when a bounded cluster wait times out */
 	int   dbg_k1h;			/* measurement only (FOSPHOR_AMD_DBG_K1H): 1 no cluster waits, 2 no IQ loads, 4 no row / bin stores,

@@ -2433,486 +2433,6 @@ void k1h_fused(const K1Params p)
 	leave();
 }
 
-/* ------------------------------------------------------------------------ */
-/* K1 for N = 65536, SPECIALISED WAVES (round 6): 12 waves per work-group -- waves 0-7 stage B + epilogue of spectrum u, waves 8-11
- * stage A of spectrum u + 1 -- three per SIMD, one of them a producer                                                          */
-/* ------------------------------------------------------------------------ */
-/* What round 6's probes say about k1h_fused (profiles/r06_c5_schedules.md): its eight waves run ONE program and reach every phase together --
- * ~7 000 cycles of address-unit issue, ~5 400 of VALU issue per SIMD and ~2 800 of LDS per spectrum and CU take turns inside a ~14 000-cycle
- * loop with two cluster-wide hand-overs in line -- and a SIMD with two waves has nothing to issue while one of them waits.  Stage A alone
- * or stage B alone in that loop take ~2/3 of its time each.  Here the two stages are different WAVES of the work-group:
- *   waves 8-11 (A): the member's 32 residues of spectrum u + 1 in two rounds of 16 (a wave does four residues per round on its own, as
- *                   before): fp16 IQ by LDS-DMA two rounds ahead (two 16 KiB buffers), first pass, transpose, second pass, stores to
- *                   the cluster's intermediate, one arrival per wave and spectrum;
- *   waves 0-7 (B):  the member's 32 offsets of spectrum u: loads of the intermediate, third pass, exchange, fourth pass, epilogue.
- * The roles meet only through the cluster's two counters (A: "every B wave has loaded spectrum n - 1" before its stores of n; B: "every A
- * wave has stored spectrum n" before its loads), so the producer runs up to a spectrum ahead with ONE intermediate per cluster, and inside the
- * work-group through nothing at all: their LDS regions are disjoint (stage A's transposes no longer share memory with stage B's exchange) and each
- * role synchronises its own waves with a counting barrier in LDS (bounded: a protocol failure ends in the error word, not in a hang); the
- * hardware barrier is used where all twelve waves meet anyway (tables, tile claims, exit).  168 registers per wave: the consumer needs no
- * second operand set (the skew is now between waves), the producer no accumulators.
- * Same plan, same arithmetic, same outputs as k1h_fused (bit for bit: the same tests run through either). */
-constexpr int kSpNT = 768;
-constexpr int kSpXb = 32 * 257;			/* stage-B exchange: [offset 32][jj3 16][a3 16], offsets padded to 257 */
-constexpr int kSpXa = 4 * kXaWave;		/* stage-A transposes: one private region per producer wave */
-constexpr int kSpIn = 256 * 16;			/* staged fp16 input of one ROUND (16 residues): [row m 256][residue 16] dwords */
-constexpr size_t kK1hSplitLds = ((size_t)kSpXb + kSpXa + 16 * kTwRow + 32 * kTwRow) * sizeof(float2) + (size_t)2 * kSpIn * sizeof(uint32_t) + (size_t)kThrMax * sizeof(double);
-
-template <bool HALF, bool WRITE_FFT>
-__global__ __launch_bounds__(kSpNT, 3)
-void k1h_split(const K1Params p)
-{
-	constexpr int N = 65536, NT = kSpNT, kMem = 8;
-	constexpr uint32_t kSpinLimit = 4u << 20;
-	constexpr uint32_t kArrA = 4 * kMem, kArrB = 8 * kMem;		/* arrivals per spectrum: every producer / consumer wave of every member */
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	v2f *xb = reinterpret_cast<v2f *>(smem_raw);				/* stage B: the consumers' exchange array */
-	v2f *xa_all = xb + kSpXb;						/* stage A: one private transpose region per producer wave */
-	v2f *twa_t = xa_all + kSpXa;						/* pass-2 twiddles [k2 16][8 of kTwRow] */
-	v2f *tw3_t = twa_t + 16 * kTwRow;					/* pass-3 twiddles of this member's 32 offsets [32][8 of kTwRow] */
-	uint32_t *inb = reinterpret_cast<uint32_t *>(tw3_t + 32 * kTwRow);	/* fp16 IQ of two rounds (two buffers of kSpIn dwords) */
-	typedef const __attribute__((address_space(3))) double *lds_cdp;
-	double *thr_g = reinterpret_cast<double *>(inb + 2 * kSpIn);
-	const lds_cdp thr_l = (lds_cdp)thr_g;
-
-	const int tid = threadIdx.x;
-	__shared__ int sh_ticket, sh_tile;
-	__shared__ uint32_t sh_bar[2];						/* the roles' counting barriers */
-	uint32_t xcc;
-	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-	xcc &= 7;
-	uint32_t *next_tile = p.sync + 63 * 64 + 56;
-	const int ntiles = p.total / p.tile;
-	if (tid == 0) {
-		sh_bar[0] = 0; sh_bar[1] = 0;
-		uint32_t *tick = p.sync + xcc * 8 * 64 + 48;
-		const uint32_t tk = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		int ok = 0;
-		if (tk < 64) {
-			uint32_t *state = p.sync + ((int)xcc * 8 + (int)(tk / kMem)) * 64 + 24;
-			uint32_t st = 0;
-			if ((tk % kMem) == kMem - 1) {
-				__hip_atomic_compare_exchange_strong(state, &st, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else {
-				uint32_t spins = 0;
-				while ((st = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
-					const bool tiles_left = (int)__hip_atomic_load(next_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ntiles;
-					if (!tiles_left || ++spins > kSpinLimit) {
-						if (tiles_left)
-							*p.sync_err = 0x80000004u;
-						uint32_t expect = 0;
-						__hip_atomic_compare_exchange_strong(state, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
-					__builtin_amdgcn_s_sleep(8);
-				}
-			}
-			ok = (st == 1);
-		}
-		sh_ticket = ok ? (int)tk : -1;
-	}
-	__syncthreads();
-	auto leave = [&]() {
-		__syncthreads();
-		if (tid == 0)
-			sh_ticket = (int)__hip_atomic_fetch_add(p.sync + 63 * 64 + 60, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__syncthreads();
-		if (sh_ticket == (int)gridDim.x - 1)
-			for (int e = tid; e < 64 * 64; e += NT)
-				__hip_atomic_store(p.sync + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	};
-	if (sh_ticket < 0) {
-		leave();
-		return;
-	}
-	const int ticket = __builtin_amdgcn_readfirstlane(sh_ticket);
-	const int member = ticket % kMem;
-	const int gc = (int)xcc * 8 + ticket / kMem;
-	uint32_t *c_a = p.sync + gc * 64;				/* producer waves that have stored their part of a spectrum */
-	uint32_t *c_t = p.sync + gc * 64 + 16;				/* (round << 20) | tile, published by member 0 */
-	uint32_t *c_b = p.sync + gc * 64 + 32;				/* consumer waves that have loaded their part of a spectrum */
-	v2f *wint = reinterpret_cast<v2f *>(p.scratch) + (size_t)gc * N;
-	const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wint);
-
-	const int lane = tid & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const bool producer = wv >= 8;					/* (wave-uniform) */
-	const v2f *twg = reinterpret_cast<const v2f *>(p.tw);
-	const v2f two = { 2.0f, 2.0f };
-
-	for (int e = tid; e <= p.n_bins && e < kThrMax; e += NT)
-		thr_g[e] = p.thr[e];
-	for (int e = tid; e < 16 * 8; e += NT)
-		twa_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[1] + e];
-	for (int e = tid; e < 32 * 8; e += NT)
-		tw3_t[(e >> 3) * kTwRow + (e & 7)] = twg[p.tw_off[2] + (32 * member) * 8 + e];
-	__syncthreads();
-
-	/* a role's own barrier: every wave of the role adds one to the role's counter and waits until it has seen all of them.  LDS
-	 * operations of a wave are performed in order, so what a wave wrote before its add is visible to whoever sees the count. */
-	uint32_t bar_seen = 0;
-	auto role_barrier = [&](int role, uint32_t waves) {
-		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-		bar_seen += waves;
-		/* (LDS instructions by hand: through a generic pointer the compiler reads the counter with flat_load_dword sc0 sc1 -- the vector
-		 * memory path, slow, and counted by vmcnt) */
-		const uint32_t ca = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)&sh_bar[role];
-		if (lane == 0)
-			asm volatile("ds_add_u32 %0, %1" :: "v"(ca), "v"(1u) : "memory");
-		uint32_t spins = 0;
-		for (;;) {
-			uint32_t v;
-			asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ca) : "memory");
-			if ((int)((uint32_t)__builtin_amdgcn_readfirstlane((int)v) - bar_seen) >= 0)
-				break;
-			if (++spins > kSpinLimit) { if (lane == 0) *p.sync_err = 0x80000005u; break; }
-			__builtin_amdgcn_s_sleep(1);
-		}
-		asm volatile("" ::: "memory");
-	};
-	auto poll = [&](const uint32_t *cnt, uint32_t target, uint32_t err) {
-		if (PROBE_K1H(p) & 1)
-			return;
-		uint32_t spins = 0;
-		while ((int)(sload_fresh(cnt) - target) < 0) {
-			if (++spins > kSpinLimit) { if (lane == 0) *p.sync_err = err; break; }	/* fail the call, not the GPU */
-			__builtin_amdgcn_s_sleep(1);
-		}
-	};
-	auto arrive = [&](uint32_t *cnt) {
-		if (lane == 0)
-			__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	};
-
-#if K1H_TIMING
-	long long hacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	long long hprev = __builtin_readcyclecounter();
-#endif
-	uint32_t done = 0;						/* spectra this role has finished since the launch began (both roles count alike) */
-	uint32_t round = 0;						/* tiles this cluster has taken */
-	/* member 0 claims the cluster's next tile; all twelve waves meet here (the hardware barrier: both roles are between tiles, and both
-	 * call this once per tile and once more to find that none is left) */
-	auto claim_tile = [&]() -> int {
-		if (tid == 0) {
-			uint32_t v;
-			if (member == 0) {
-				v = __hip_atomic_fetch_add(next_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (v > 0xfffffu) v = 0xfffffu;
-				__hip_atomic_store(c_t, ((round + 1) << 20) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else {
-				uint32_t spins = 0;
-				while (((v = __hip_atomic_load(c_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 20) != round + 1) {
-					if (++spins > kSpinLimit) { *p.sync_err = 0x80000001u; v = 0xfffffu; break; }
-					__builtin_amdgcn_s_sleep(2);
-				}
-				v &= 0xfffffu;
-			}
-			sh_tile = (int)v;
-		}
-		__syncthreads();
-		const int tl = __builtin_amdgcn_readfirstlane(sh_tile);
-		__syncthreads();				/* (sh_tile may be written again) */
-		round++;
-		return tl;
-	};
-
-	if (producer) {
-		/* =================== stage A: residues 32 member + 16 r + 4 w + sa, r = 0, 1 (rounds), w = wave - 8 ===================
-		 * pass-1 item a = lane & 15 reads m = a + 16 j; after the wave's own 16 x 16 transpose the same lane is pass-2 item k2 = lane & 15 */
-		const int w = wv - 8;
-		const int sa = lane >> 4, ia = lane & 15;
-		const int qa0 = 32 * member + 4 * w + sa;			/* round 0; round 1: + 16 */
-		const unsigned wst0 = 8u * (unsigned)(qa0 * 32 + (ia ^ ((qa0 & 1) << 4)));	/* [offset / 32][residue][offset % 32 ^ 16 (residue & 1)], byte offsets */
-		const unsigned wst1 = wst0 ^ 128u;
-		const v2f w16c = twg[p.tw_off[0]], w8c = twg[p.tw_off[0] + 1], w163c = twg[p.tw_off[0] + 2];
-		v2f wab[2][HALF ? 8 : 1];
-#pragma unroll
-		for (int r = 0; r < 2; r++)
-#pragma unroll
-			for (int j = 0; j < (HALF ? 8 : 1); j++)
-				wab[r][j] = v2f{ p.win[qa0 + 16 * r + 256 * (ia + 16 * j)], p.win[qa0 + 16 * r + 256 * (ia + 16 * (j + 8))] };
-		v2f *xa = xa_all + w * kXaWave;
-		const int ea_w = sa * 272 + ia, ea_r = sa * 272 + ia * 17;
-		const v2f *twa_r = twa_t + ia * kTwRow;
-		__builtin_amdgcn_s_setprio(1);				/* (the producer is the shorter program: it goes first when it can) */
-		typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-		/* LDS-DMA of one round: 256 rows x 64 B (16 residues); one wave-instruction lands 16 rows; piece pc of row m at slot 4 m + (pc ^ ((m >> 2) & 3)) */
-		const uint32_t iq_vo = 1024u * (unsigned)(lane >> 2) + 16u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
-		const int in_rd = ia * 16 + ((w ^ ((ia >> 2) & 3)) << 2) + sa;		/* + 256 j: row m = ia + 16 j (dwords) */
-		const uint32_t inb_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)inb;
-		auto fetch_round = [&](int t, int r, int buf) {			/* four wave-instructions per wave: row groups g = w, w + 4, w + 8, w + 12 */
-			if (!HALF || (PROBE_K1H(p) & 2))
-				return;
-			const uint32_t *src = reinterpret_cast<const uint32_t *>(p.iq) + (size_t)t * p.hop + 32 * member + 16 * r;
-#pragma unroll
-			for (int g4 = 0; g4 < 4; g4++) {
-				const int g = w + 4 * g4;
-				const uint32_t *sk = src + 256 * 16 * g;
-				const uint32_t la = inb_lds + 4u * (unsigned)(buf * kSpIn + 256 * g);
-				uint32_t keep;
-				asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 " K1H_IQ_MOD "\n\ts_mov_b32 m0, %0"
-				             : "=&s"(keep) : "v"(iq_vo), "s"(sk), "s"(la) : "memory");
-			}
-		};
-		for (;;) {
-		const int tile = claim_tile();
-		if (tile >= ntiles)
-			break;
-		const int t0 = tile * p.tile;
-		/* the tile's rounds kk = 2 s + r; round kk's input sits in buffer kk & 1 and is requested two rounds ahead -- ALWAYS (behind the tile's
-		 * last round: of that round again, unused), so that every round issues the same vector-memory operations and the waits can be counted */
-		const int nrounds = 2 * p.tile;
-		auto round_t = [&](int kk) { return t0 + ((kk < nrounds ? kk : nrounds - 1) >> 1); };
-		auto round_r = [&](int kk) { return (kk < nrounds ? kk : nrounds - 1) & 1; };
-		fetch_round(round_t(0), round_r(0), 0);
-		fetch_round(round_t(1), round_r(1), 1);
-#pragma unroll 1
-		for (int kk = 0; kk < nrounds; kk++) {
-			const int t = t0 + (kk >> 1), r = kk & 1, buf = kk & 1;
-			v2f ra[16];
-			K1H_STAMP(0);		/* loop overhead */
-			/* this wave's requests of round kk have landed: everything it has issued SINCE may stay in flight -- the other round's requests (4),
-			 * a round's stores (16), an arrival (1) */
-			if (HALF && !PROBE_K1H(p)) {
-				if (kk == 0)      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-				else if (kk == 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-				else              asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
-			} else {
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			}
-			K1H_STAMP(1);		/* A: own IQ requests landed */
-			role_barrier(0, 4);				/* ... and everybody else's */
-			K1H_STAMP(2);		/* A: barrier (requests of the others) */
-			const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(p.iq + (size_t)t * p.hop);
-#pragma unroll
-			for (int jo = 0; jo < 16; jo++) {
-				const int j = K1H_PAIR(jo);
-				v2f xv;
-				if (HALF) {
-					const uint32_t raw = inb[buf * kSpIn + in_rd + 256 * j];
-					const h2 h = __builtin_bit_cast(h2, raw);
-					xv = v2f{ (float)h.x, (float)h.y };
-				} else {
-					xv = bld_v2f<kAuxNT>(rs_f, 8u * (unsigned)(qa0 + 16 * r + 256 * ia), 32768u * j);
-				}
-				ra[j] = xv;
-			}
-			K1H_STAMP(3);		/* A: LDS reads of the staged IQ */
-			role_barrier(0, 4);				/* every producer wave has its rows out of the buffer */
-			K1H_STAMP(4);		/* A: barrier (buffer free) */
-			if constexpr (HALF) {
-				if (r == 0) pass16_first<K1H_SC, false>(ra, wab[0], w16c, w8c, w163c, two);
-				else        pass16_first<K1H_SC, false>(ra, wab[1], w16c, w8c, w163c, two);
-			} else {
-				v2f wl[8];
-#pragma unroll
-				for (int j = 0; j < 8; j++)
-					wl[j] = v2f{ p.win[qa0 + 16 * r + 256 * (ia + 16 * j)], p.win[qa0 + 16 * r + 256 * (ia + 16 * (j + 8))] };
-				pass16_first<K1H_SC, false>(ra, wl, w16c, w8c, w163c, two);
-			}
-#pragma unroll
-			for (int jj = 0; jj < 16; jj++)
-				xa[ea_w + 17 * jj] = ra[R16_PERM(jj)];
-			wave_lds_sync();
-#pragma unroll
-			for (int jo = 0; jo < 16; jo++)
-				ra[K1H_PAIR(jo)] = xa[ea_r + K1H_PAIR(jo)];
-			wave_lds_sync();
-			pass16_ab<K1H_SC, false>(ra, twa_r[0], twa_r[1], two);
-			pass16_cd<K1H_SC, false>(ra, twa_r[2], twa_r[3], twa_r[4], twa_r[5], twa_r[6], twa_r[7], two);
-			K1H_STAMP(5);		/* A: first pass, transpose, second pass */
-			/* the intermediate is free: every consumer wave of every member has loaded the spectrum before this one */
-			if (r == 0)
-				poll(c_b, kArrB * done, 0x80000002u);
-			K1H_STAMP(6);		/* A: "intermediate free?" */
-			if (!(PROBE_K1H(p) & (8 | 512))) {
-				const uint32_t ro = 4096u * (uint32_t)r;	/* residue + 16: 16 rows of 256 B further */
-#pragma unroll
-				for (int jj = 0; jj < 16; jj++)
-					bst_v2f<0>(ra[R16_PERM(jj)], rs_w, (jj & 1) ? wst1 : wst0, ro + 65536u * (jj >> 1));
-			}
-			fetch_round(round_t(kk + 2), round_r(kk + 2), buf);	/* (behind the stores: their acknowledgements are waited for, this is not) */
-			K1H_STAMP(7);		/* A: stores + IQ requests issued */
-			if (r == 1) {
-				if (HALF && !PROBE_K1H(p)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");	/* both rounds' stores are in the L2 */
-				else                       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				arrive(c_a);
-				done++;
-			}
-			K1H_STAMP(8);		/* A: stores acknowledged, arrival */
-		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	/* nothing of this tile is still on its way into LDS */
-		role_barrier(0, 4);
-		}
-	} else {
-		/* =================== stage B: offsets kk = 32 member + (tid & 31), pass-3 item a3 = tid >> 5, then pass-4 item jj3 = tid >> 5 ===================
-		 * columns kk + 256 jj3 + 4096 jj4 */
-		const BinConst bk = { p.binA, p.binC, p.amb, p.kappa, p.n_bins, p.thr };
-		const float vmax_init = -1000.0f / F_HALF_LOG10_2;
-		const float top = (float)(bk.nb - 1);
-		const int kkl = tid & 31, ib = tid >> 5;
-		const int kk = 32 * member + kkl;
-		const unsigned ucol0 = (unsigned)(kk + 256 * ib);
-		const unsigned wld = 8u * (unsigned)(ib * 32 + (kkl ^ ((ib & 1) << 4)));
-		const __amdgpu_buffer_rsrc_t rs_wf = make_rsrc(p.wf), rs_part = make_rsrc(p.partial);
-		v2f tw4[8];
-#pragma unroll
-		for (int j = 0; j < 8; j++)
-			tw4[j] = twg[p.tw_off[3] + (kk + 256 * ib) * 8 + j];
-		const v2f *tw3_r = tw3_t + kkl * kTwRow;
-		const int eb_w = kkl * 257 + ib, eb_r = kkl * 257 + ib * 16;
-		uint32_t *bins_lo = p.bins;
-		uint32_t *bins_hi = p.bins + (size_t)(p.total >> 2) * N;
-		if (wv >= 4)
-			__builtin_amdgcn_s_setprio(0);
-		for (;;) {
-		const int tile = claim_tile();
-		if (tile >= ntiles)
-			break;
-		const int t0 = tile * p.tile;
-		float live[16], vmax[16];
-		uint32_t plo[16], phi[16];
-#pragma unroll
-		for (int c = 0; c < 16; c++) { live[c] = 0.0f; vmax[c] = vmax_init; plo[c] = 0; phi[c] = 0; }
-#pragma unroll 1
-		for (int u = 0; u < p.tile; u++) {
-			const int t = t0 + u;
-			K1H_STAMP(0);
-			poll(c_a, kArrA * (done + 1), 0x80000003u);	/* every producer wave of the cluster has stored its part of this spectrum */
-			K1H_STAMP(1);		/* B: "spectrum stored?" */
-			v2f r[16];
-			if (!(PROBE_K1H(p) & (8 | 256))) {
-#pragma unroll
-				for (int jo = 0; jo < 16; jo++)
-					r[K1H_PAIR(jo)] = bld_v2f<kAuxSC1>(rs_w, wld, 65536u * member + 4096u * K1H_PAIR(jo));
-			} else {
-#pragma unroll
-				for (int j = 0; j < 16; j++)
-					r[j] = v2f{ 0.01f * (float)((tid + j) & 63), 0.02f };
-			}
-			K1H_STAMP(2);		/* B: loads issued */
-			pass16_ab<K1H_SC, false>(r, tw3_r[0], tw3_r[1], two);				/* pass 3, p = 256, k = kk */
-#if K1H_TIMING
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-			K1H_STAMP(3);		/* B: third pass A, B incl. the wait for the loads */
-			arrive(c_b);									/* this wave's loads have landed (all sixteen were used) */
-			done++;
-			pass16_cd<K1H_SC, false>(r, tw3_r[2], tw3_r[3], tw3_r[4], tw3_r[5], tw3_r[6], tw3_r[7], two);
-#pragma unroll
-			for (int jj = 0; jj < 16; jj++)
-				xb[eb_w + 16 * jj] = r[R16_PERM(jj)];
-			K1H_STAMP(4);		/* B: third pass C, D + exchange stores */
-			role_barrier(1, 8);
-			K1H_STAMP(5);		/* B: barrier (exchange written) */
-#pragma unroll
-			for (int jo = 0; jo < 16; jo++)
-				r[K1H_PAIR(jo)] = xb[eb_r + K1H_PAIR(jo)];
-			K1H_STAMP(6);		/* B: exchange loads */
-			role_barrier(1, 8);				/* (the exchange array may be written again: the next spectrum's third pass is a long way off) */
-			K1H_STAMP(7);		/* B: barrier (exchange read) */
-			pass16_ab<K1H_SC, false>(r, tw4[0], tw4[1], two);					/* pass 4, p = 4096, k = kk + 256 ib */
-			pass16_cd<K1H_SC, false>(r, tw4[2], tw4[3], tw4[4], tw4[5], tw4[6], tw4[7], two);
-
-			K1H_STAMP(8);		/* B: fourth pass */
-			if (WRITE_FFT) {
-#pragma unroll
-				for (int c = 0; c < 16; c++)
-					bst_v2f<0>(r[R16_PERM(c)], make_rsrc(reinterpret_cast<v2f *>(p.fft_out) + (size_t)t * N), 8u * ucol0, 32768u * c);
-			}
-			/* epilogue (display.cl:136-150,161-168), as in k1h_fused */
-			const bool store_row = (t >= p.wf_first) && !(PROBE_K1H(p) & 4);
-			const uint32_t wf_so = (uint32_t)((p.wf_pos0 + t) & p.wf_mask) * (uint32_t)(N * 4);
-			const int sh8 = 8 * (u & 3);
-#pragma unroll
-			for (int g = 0; g < 4; g++) {
-				float l2g[4]; uint32_t bng[4]; uint32_t amb = 0;
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const v2f x = r[R16_PERM(4 * g + k)];
-					uint32_t ab;
-					const float rr = bin_fast(x.x, x.y, bk, &l2g[k], &ab);
-					amb = amb > ab ? amb : ab;
-					bng[k] = (uint32_t)(int)__builtin_amdgcn_fmed3f(rr, 0.0f, top);
-				}
-				if (amb > __float_as_uint(bk.amb) && !(PROBE_K1H(p) & 16)) {
-#pragma unroll
-					for (int k = 0; k < 4; k++) {
-						const v2f x = r[R16_PERM(4 * g + k)];
-						const float v = __builtin_fmaf(bk.A, l2g[k], bk.C);
-						const float a = __builtin_fmaf(__builtin_fabsf(l2g[k]), bk.kappa, __builtin_fabsf(v - __builtin_rintf(v)));
-						if (!(a <= bk.amb)) {
-							float nl2;
-							bng[k] = bin_exact(x.x, x.y, l2g[k], (int)bng[k], thr_l, bk.nb, &nl2);
-							l2g[k] = nl2;
-						}
-					}
-				}
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const int c = 4 * g + k;
-					const uint32_t bn = bng[k];
-					const float l2v = l2g[k];
-					plo[c] |= (bn & 0xffu) << sh8;
-					phi[c] |= (bn >> 8) << u;
-					live[c] = __builtin_fmaf(live[c], p.w, l2v);
-					vmax[c] = max_f32(vmax[c], l2v);
-					if (store_row)
-						__builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l2v * F_HALF_LOG10_2), rs_wf, 4u * ucol0, wf_so + 16384u * c, K1H_OUT_AUX);
-				}
-			}
-			if ((u & 3) == 3 && !(PROBE_K1H(p) & 4)) {
-				const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(bins_lo + (size_t)(t >> 2) * N);
-#pragma unroll
-				for (int c = 0; c < 16; c++) {
-					__builtin_amdgcn_raw_buffer_store_b32(plo[c], rs_lo, 4u * ucol0, 16384u * c, K1H_OUT_AUX);
-					plo[c] = 0;
-				}
-			}
-			K1H_STAMP(9);		/* B: epilogue */
-		}
-		if (!(PROBE_K1H(p) & 4)) {
-			const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(bins_hi + (size_t)tile * N);
-#pragma unroll
-			for (int c = 0; c < 16; c++)
-				__builtin_amdgcn_raw_buffer_store_b32(phi[c], rs_hi, 4u * ucol0, 16384u * c, K1H_OUT_AUX);
-		}
-#pragma unroll
-		for (int c = 0; c < 16; c++)
-			bst_v2f<0>(v2f{ live[c] * F_HALF_LOG10_2, (vmax[c] == vmax_init) ? -1000.0f : vmax[c] * F_HALF_LOG10_2 },
-			           rs_part, 8u * ucol0, (uint32_t)tile * (uint32_t)(N * 8) + 32768u * c);
-		}
-	}
-#if K1H_TIMING
-	if (p.dbg && lane == 0 && (wv == 0 || wv == 7 || wv == 8)) {		/* two consumers, one producer */
-		const int slot = (wv == 0) ? 0 : (wv == 7) ? 1 : 2;
-		for (int i = 0; i < 16; i++)
-			p.dbg[((size_t)blockIdx.x * 3 + slot) * 16 + i] = hacc[i];
-	}
-#endif
-	leave();
-}
-
-static hipError_t launch_k1h_split(const K1Params &p0, hipStream_t s)
-{
-	typedef void (*k1h_fn)(const K1Params);
-	static const k1h_fn fn[4] = { k1h_split<false, false>, k1h_split<true, false>, k1h_split<false, true>, k1h_split<true, true> };
-	static unsigned long long attr_dev = 0;
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-		return hipErrorInvalidDevice;
-	if (!(attr_dev >> dev & 1)) {
-		for (int i = 0; i < 4; i++) {
-			const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn[i]), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kK1hSplitLds);
-			if (e != hipSuccess)
-				return e;
-		}
-		attr_dev |= 1ull << dev;
-	}
-	hipLaunchKernelGGL(fn[(p0.iq_half ? 1 : 0) | (p0.fft_out ? 2 : 0)], dim3(256), dim3(kSpNT), kK1hSplitLds, s, p0);
-	return hipGetLastError();
-}
-
 template <int NWV>
 static hipError_t launch_k1h_form(const K1Params &p0, hipStream_t s)
 {
@@ -2943,7 +2463,7 @@ static hipError_t launch_k1h(const K1Params &p0, hipStream_t s)
 	/* tiles of 4 .. 32 spectra (whole quads of low bytes, the 9th bits of a tile in one dword); tile index: 20 bits of the claim word */
 	if (!p0.sync || !p0.scratch || p0.tile < 4 || p0.tile > 32 || (p0.tile & 3) || p0.total % p0.tile || p0.total / p0.tile >= (1 << 20))
 		return hipErrorInvalidValue;
-	return p0.k1h_form == 1 ? launch_k1h_form<8>(p0, s) : launch_k1h_split(p0, s);
+	return launch_k1h_form<8>(p0, s);
 }
 
 

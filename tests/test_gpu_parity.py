@@ -1330,14 +1330,11 @@ def test_c3_geometry_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, overl
     f.close()
 
 
-@pytest.mark.parametrize("form", ["0", "1"])
-def test_fft65536_bit_exact(amd, torch_cuda, oracle_built, monkeypatch, form):
-    """(form 0: specialised waves, k1h_split, the default; form 1: one program for all eight waves, k1h_fused)
-    N = 65536 in two 256-point levels (passes p = 1, 16 per residue mod 256 inside a wavefront; passes p = 256, 4096 per
+def test_fft65536_bit_exact(amd, torch_cuda, oracle_built):
+    """N = 65536 in two 256-point levels (passes p = 1, 16 per residue mod 256 inside a wavefront; passes p = 256, 4096 per
     offset mod 256 in a work-group; the spectrum between them in the XCD's L2): the bits of the oracle's radix-16 plan of FMA butterflies
     (this build's own plan at this length: no reference behaviour exists), fp32 and fp16 input."""
     torch = torch_cuda
-    monkeypatch.setenv("FOSPHOR_AMD_K1H_FORM", form)
     n = 65536
     o = Oracle(fft_len_log=16, n_bins=512, wf_rows=64)
     x = gaussian_iq(8 * n, 90, sigma=1.0).reshape(8, n, 2)
@@ -1637,7 +1634,7 @@ def _c5_outputs(f):
     return [canon_bits(f.waterfall), canon_bits(f.histogram), canon_bits(f.spectrum), f.hitcount.copy()]
 
 
-@pytest.mark.parametrize("tile", [None, "4", "16", "nomask", "fused", "fused-4"])
+@pytest.mark.parametrize("tile", [None, "4", "16", "nomask"])
 def test_c5_call_shapes_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, tile):
     """N = 65536 (fp16 IQ, 512 bins) through the fused two-level kernel (clusters of 8 work-groups per XCD, the intermediate
     spectrum resident in the XCD's L2) over calls whose tile counts do not divide evenly among the clusters, multi-batch calls
@@ -1648,10 +1645,6 @@ def test_c5_call_shapes_vs_oracle(amd, torch_cuda, oracle_built, monkeypatch, ti
     threads = min(os.cpu_count() or 1, 64)
     monkeypatch.delenv("FOSPHOR_AMD_TILE", raising=False)
     monkeypatch.delenv("FOSPHOR_AMD_ROWMASK", raising=False)
-    monkeypatch.delenv("FOSPHOR_AMD_K1H_FORM", raising=False)
-    if tile and tile.startswith("fused"):		# the one-program form of the FFT kernel (k1h_fused) instead of the specialised waves
-        monkeypatch.setenv("FOSPHOR_AMD_K1H_FORM", "1")
-        tile = tile[6:] or None
     if tile == "nomask":
         tile = None
         monkeypatch.setenv("FOSPHOR_AMD_ROWMASK", "0")

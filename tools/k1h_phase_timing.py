@@ -29,26 +29,12 @@ wgs = 256
 out = np.zeros(wgs * 3 * 16, np.int64)
 assert L.fosphor_amd_debug_k1_timing(f.h, out.ctypes.data, out.size) == 0
 t = out.reshape(wgs, 3, 16).astype(np.float64)
-form = os.environ.get("FOSPHOR_AMD_K1H_FORM", "0")
-if form == "1":		# one program for all eight waves (k1h_fused): waves 0 / 3 / 7
-    cols = "first / middle / last wave"
-    names = [["loop overhead / tile claim", "own look at 'intermediate read by all?'", "stores + pass 1 (next)", "wait stores acked (+IQ DMA)", "barrier + arrive",
-              "transpose (+pass 2 part)", "cluster barrier: poll + wg barrier", "loads issued + pass 2 (next)", "pass 3 AB incl. load wait",
-              "IQ request + pass 3 CD + xb stores", "exchange barrier", "xb loads + pass 4", "-", "epilogue", "-", "-"]] * 3
-else:			# specialised waves (k1h_split): consumer waves 0 and 7, producer wave 8 (its rows are per ROUND: two per spectrum)
-    cols = "consumer wave 0 / consumer wave 7 / producer wave 8"
-    nb = ["loop overhead", "poll: spectrum stored?", "loads issued", "pass 3 AB incl. load wait", "pass 3 CD + exchange stores", "barrier (exchange written)",
-          "exchange loads", "barrier (exchange read)", "pass 4", "epilogue", "-", "-", "-", "-", "-", "-"]
-    na = ["loop overhead", "own IQ requests landed", "barrier (others' requests)", "LDS reads of the staged IQ", "barrier (buffer free)", "pass 1, transpose, pass 2",
-          "poll: intermediate free?", "stores + IQ requests issued", "stores acknowledged + arrival", "-", "-", "-", "-", "-", "-", "-"]
-    names = [nb, nb, na]
+names = ["loop overhead / tile claim", "own look at 'intermediate read by all?'", "stores + pass 1 (next)", "wait stores acked (+IQ DMA)", "barrier + arrive",
+         "transpose (+pass 2 part)", "cluster barrier: poll + wg barrier", "loads issued + pass 2 (next)", "pass 3 AB incl. load wait",
+         "IQ request + pass 3 CD + xb stores", "exchange barrier", "xb loads + pass 4", "-", "epilogue", "-", "-"]
 live = t[:, 0, :].sum(1) > 0		# work-groups whose cluster did work
 spw = total / 32.0			# spectra per cluster (mean)
-print("form %s; work-groups with work: %d of %d; s_memtime cycles per spectrum (mean over them), %s:" % (form, live.sum(), wgs, cols))
-for i in range(14):
-    v = [t[live, s, i].mean() / spw for s in range(3)]
-    if form == "1":
-        print("  %-38s %8.0f %8.0f %8.0f" % (names[0][i], *v))
-    else:
-        print("  %-32s %8.0f %8.0f   | %-32s %8.0f" % (nb[i], v[0], v[1], na[i], v[2]))
+print("work-groups with work: %d of %d; s_memtime cycles per spectrum (mean over them), first / middle / last wave:" % (live.sum(), wgs))
+for i, nm in enumerate(names[:14]):
+    print("  %-38s %8.0f %8.0f %8.0f" % (nm, *[t[live, s, i].mean() / spw for s in range(3)]))
 print("  %-38s %8.0f %8.0f %8.0f" % ("total", *[t[live, s, :].sum(1).mean() / spw for s in range(3)]))
