@@ -638,7 +638,7 @@ def measure_sink(ctx, seconds=2.0):
     (1024-pt FFT, the reference's 128 bins), host samples in pageable memory as a GNU Radio buffer would be:
       work_fifo      gr::fosphor::base_sink_c::work() -> fifo -> render(): fosphor_process() (base_sink_c_impl.cc:130-201,432-462)
                      as the GNU-Radio-free runtime does it (fosphor_sink.cpp: pinned FIFO, uploads on their own stream, up to 8 batches
-                     per call), fed by a native thread in work() calls of 64 Ki samples for >= `seconds`;
+                     per call), fed by a native thread in work() calls of 64 Ki samples for >= `seconds` (and of 1 Mi samples for half that);
       process_calls  plain fosphor_process(self, samples, 1 Mi) calls from host memory (the literal reference call shape,
                      base_sink_c_impl.cc:146-175 -> cl.c:903-910), one fosphor_draw() per 8 calls, for >= `seconds`."""
     import ctypes as C
@@ -656,16 +656,21 @@ def measure_sink(ctx, seconds=2.0):
             raise RuntimeError("sink did not start")
         if L.fosphor_amd_sink_feed(s, x.ctypes.data, n, 64 * 1024, 1) < 0:	# warm-up (boot, staging buffers)
             raise RuntimeError("sink consumed nothing")
-        reps, dt = 0, 0.0
-        while dt < seconds:
-            d = L.fosphor_amd_sink_feed(s, x.ctypes.data, n, 64 * 1024, 4)
-            if d < 0:
-                raise RuntimeError("sink stalled")
-            dt += d
-            reps += 4
-        v = n * reps / dt / 1e6
-        out["work_fifo"] = {"value": v, "seconds": dt, "samples": n * reps, "frac_of_link": v * 8e6 / (PCIE_GEN5_X16_GBS * 1e9),
-                            "dropped": int(L.fosphor_amd_sink_dropped(s)), "work_call_samples": 64 * 1024, "fifo_samples": 1 << 24}
+        def leg(chunk, budget):
+            reps, dt = 0, 0.0
+            while dt < budget:
+                d = L.fosphor_amd_sink_feed(s, x.ctypes.data, n, chunk, 4)
+                if d < 0:
+                    raise RuntimeError("sink stalled")
+                dt += d
+                reps += 4
+            v = n * reps / dt / 1e6
+            return {"value": v, "seconds": dt, "samples": n * reps, "frac_of_link": v * 8e6 / (PCIE_GEN5_X16_GBS * 1e9),
+                    "dropped": int(L.fosphor_amd_sink_dropped(s)), "work_call_samples": chunk, "fifo_samples": 1 << 24}
+        out["work_fifo"] = leg(64 * 1024, seconds)
+        # the same with work() handed 1 Mi samples at a time (one memcpy of 8 MiB per call: what bounds the single producer thread
+        # at 64 Ki is its per-call cost, not the link)
+        out["work_fifo_1Mi_calls"] = leg(1 << 20, seconds / 2)
         L.fosphor_amd_sink_stop(s)
     finally:
         L.fosphor_amd_sink_free(s)
