@@ -113,7 +113,8 @@ int fosphor_amd_get_buffers_nohc(struct fosphor *self, struct fosphor_amd_buffer
 int fosphor_amd_read(struct fosphor *self, int which, void *host, uint64_t bytes);
 
 /* Kernel-level test hook: windowed forward FFT only (the fft1D_1024 contract,
- * fft.cl:397-466): d_in, d_out are float2[n_spectra][N] device buffers. */
+ * fft.cl:397-466): d_in, d_out are float2[n_spectra][N] device buffers; n_spectra a multiple of 4
+ * (of 8 at fft_len_log = 13), at most max_spectra; -EINVAL otherwise. */
 int fosphor_amd_fft(struct fosphor *self, const void *d_in, void *d_out, int n_spectra);
 
 /* Kernel-level test hook: per-sample bin index and approximate log-power of FFT
