@@ -91,7 +91,7 @@ struct fosphor
 	int       pp;
 	hipStream_t k1_streams[kMaxK1Streams];	/* [0] = `stream`; the K1s of consecutive sub-launches of a device-resident call rotate over
 						 * n_k1_streams of them: the next K1s are already queued when work-groups of the current one exit */
-	int       n_sets;			/* FOSPHOR_AMD_SETS (default 3): intermediate sets in use, <= kSets */
+	int       n_sets;			/* intermediate sets in use (3, <= kSets) */
 	int       n_k1_streams;			/* FOSPHOR_AMD_K1_STREAMS (default 2) */
 	hipEvent_t ev_k1s_done[kMaxK1Streams];
 	int       alt;				/* FOSPHOR_AMD_ALT=0 keeps every K1 on `stream` */
@@ -118,7 +118,6 @@ struct fosphor
 	int       k1_variant;			/* FOSPHOR_AMD_K1: 1 (default) = wave per spectrum, 2 = two waves per spectrum (what odd hops use) */
 	/* tuning / test knobs, read from the environment ONCE, at init (nothing on the submit path calls getenv) */
 	int       kn_tile;			/* FOSPHOR_AMD_TILE: spectra per tile, 0 = pick_tile's choice */
-	int       kn_no_bigchunk;		/* FOSPHOR_AMD_NO_BIGCHUNK */
 	int       kn_rowmask_off;		/* FOSPHOR_AMD_ROWMASK=0: dense count hand-off at N = 65536 */
 	int       kn_no_sum16;			/* FOSPHOR_AMD_NO_SUM16 */
 	int       kn_frame_group;		/* FOSPHOR_AMD_FRAME_GROUP: chunks per count work-group of a sharded frame (default 4) */
@@ -334,20 +333,19 @@ static void build_thresholds(double *thr, int nb, float hs, float ho)
 /* Output streams of the 65536-point kernel (waterfall rows, bin indices) live in UNCACHED device memory: its clusters keep their
  * intermediate in the XCD's L2 and every byte streamed through that L2 pushes intermediate lines out, to be written back to HBM although
  * they are dead.  Uncached stores go past the L2: WRITE_SIZE per 1024-spectrum frame 649 -> 541 MiB at the same kernel time (DESIGN.md
- * section 8; FOSPHOR_AMD_UC_OUTPUTS=0 for the A/B).  The other configurations have no such hot set and keep plain memory (the 8192-point
+ * section 8; A/B'd in round 4 through an environment switch that has since gone).  The other configurations have no such hot set and keep plain memory (the 8192-point
  * kernel's index stores run 6 % slower uncached). */
 static hipError_t alloc_output(void **p, size_t bytes, bool uncached)
 {
-	const char *e = getenv("FOSPHOR_AMD_UC_OUTPUTS");
-	if (uncached && !(e && *e == '0') && hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess)
+	if (uncached && hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached) == hipSuccess)
 		return hipSuccess;
 	return hipMalloc(p, bytes);
 }
 
 static unsigned dep_event_flags(void)
 {
-	const char *e = getenv("FOSPHOR_AMD_SYSFENCE");
-	return (e && *e == '1') ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+	/* (no system fence: the events order kernels of this device among its own streams, nothing the host or another device reads) */
+	return hipEventDisableTiming | hipEventDisableSystemFence;
 }
 
 extern "C" const char *fosphor_amd_version(void) { return FOSPHOR_AMD_VERSION; }
@@ -486,7 +484,6 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 	{
 		const char *e;
 		e = getenv("FOSPHOR_AMD_TILE");        self->kn_tile = e ? atoi(e) : 0;
-		self->kn_no_bigchunk = getenv("FOSPHOR_AMD_NO_BIGCHUNK") != NULL;
 		e = getenv("FOSPHOR_AMD_ROWMASK");     self->kn_rowmask_off = (e && *e == '0');
 		self->kn_no_sum16 = getenv("FOSPHOR_AMD_NO_SUM16") != NULL;
 		e = getenv("FOSPHOR_AMD_FRAME_GROUP"); self->kn_frame_group = e ? atoi(e) : 4;
@@ -605,8 +602,7 @@ extern "C" struct fosphor *fosphor_amd_init(const struct fosphor_amd_config *cfg
 		self->pipe3 = e ? (*e == '1') : (self->log2n == 16);	/* (N = 65536: merge on its own stream, above) */
 		e = getenv("FOSPHOR_AMD_ALT");
 		self->alt = !(e && *e == '0');
-		e = getenv("FOSPHOR_AMD_SETS");
-		self->n_sets = (e && atoi(e) >= 2 && atoi(e) <= kSets) ? atoi(e) : 3;
+		self->n_sets = 3;		/* (of kSets allocated: more in rotation measured nothing) */
 		if (self->log2n == 13 && !getenv("FOSPHOR_AMD_K1_STREAMS"))
 			self->n_k1_streams = 1;		/* a second FFT launch in flight would take the CUs left to count / merge */
 		if (self->n_k1_streams == 1)
@@ -922,7 +918,7 @@ static void fill_k1(struct fosphor *self, K1Params *k1, const void *d_iq, int to
  * then reads slab-major 16-bit counts (0.5 B per cell) instead of 32-bit sums of per-chunk slabs. */
 static int count_one_chunk(const struct fosphor *self, int batch, int n_batches)
 {
-	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128 && !self->kn_no_bigchunk;
+	return batch > 1024 && batch <= kRiseMax && (self->n / 64) * n_batches >= 128;
 }
 
 /* Sparse K2 -> K3 hand-off (row masks + hot flags) for the large state of N = 65536 (128 MiB, one batch = one frame: +10 % for

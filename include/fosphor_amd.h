@@ -92,7 +92,7 @@ int fosphor_amd_finish(struct fosphor *self);
  * every row of the ring does so in the other one, see fosphor_amd_set_input_ordering).
  * At fft_len_log = 16 the waterfall rings are UNCACHED device memory (hipDeviceMallocUncached: the kernel's row stores must not
  * pass through the L2 that holds its intermediate, DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8): any kernel or copy may read them, reads simply are not
- * cached (FOSPHOR_AMD_UC_OUTPUTS=0 in the environment gives plain memory). */
+ * cached. */
 struct fosphor_amd_buffers
 {
 	float    *d_waterfall;
