@@ -1839,8 +1839,9 @@ void k1w_fft_bin(const K1Params p)
  *   - that LDS-DMA is issued by hand (inline asm): the compiler parks every barrier and LDS read that follows an LDS-DMA it knows
  *     about behind s_waitcnt vmcnt(0); the reads of the buffer sit behind an explicit vmcnt(0) of the requesting wave + a barrier;
  *   - work-group barriers are s_waitcnt lgkmcnt(0) + s_barrier (wg_barrier_lds): __syncthreads() would drain vmcnt;
- *   - the polls of the cluster counters are loads too: the "has everybody read the intermediate" poll is made by the last wave,
- *     which requests no IQ, before its epilogue's stores;
+ *   - a poll of a cluster counter through the vector path is a load too (it returns behind whatever its wave has in flight): the "has
+ *     everybody read the intermediate" question therefore goes through the SCALAR path, every wave for itself (K1H_SPOLL, round 6; until
+ *     round 5 the last wave, which requested no IQ, asked ahead of its epilogue's stores and a barrier passed the answer on);
  *   - the exact path's threshold table sits in LDS (ds_read has its own counter). */
 
 /* Loads return IN ORDER and the first stage of a radix-16 pass pairs inputs j and j + 8: requested in this order, a butterfly's two inputs
