@@ -1318,8 +1318,18 @@ constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of
 #ifndef K1H_OUT_AUX
 #define K1H_OUT_AUX 2				/* cache policy of the 65536-point kernel's row / index stores (A/B builds) */
 #endif
-#ifndef K1H_IQ_MOD
-#define K1H_IQ_MOD "nt"				/* ... and of its LDS-DMA of the IQ */
+#ifndef K1H_IQ_MOD				/* ... and of its LDS-DMA of the IQ (K1H_IQ_POL: A/B builds) */
+#if !defined(K1H_IQ_POL) || K1H_IQ_POL == 0
+#define K1H_IQ_MOD "nt"
+#elif K1H_IQ_POL == 1
+#define K1H_IQ_MOD ""
+#elif K1H_IQ_POL == 2
+#define K1H_IQ_MOD "sc1"
+#elif K1H_IQ_POL == 3
+#define K1H_IQ_MOD "sc0 sc1"
+#else
+#define K1H_IQ_MOD "sc0 sc1 nt"
+#endif
 #endif
 template <int AUX>
 static __device__ __forceinline__ void bst_v2f(v2f v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
