@@ -2669,11 +2669,15 @@ void k2_count(const K2Params p)
 		const uint32_t *hi = p.bins + (size_t)(p.total >> 2) * n + (size_t)c * ntl * n + x0 + lane;
 #pragma unroll 1
 		for (uint32_t tl = wv; tl < ntl; tl += NW) {
-			const uint32_t hv = hi[(size_t)tl * n];
+#ifndef K2_NT9
+#define K2_NT9 1		/* (0: A/B builds) the index planes of N = 65536 read non-temporally (they are read once; the FFT kernel of the next frame keeps its
+				 * intermediates in the same L2) */
+#endif
+			const uint32_t hv = K2_NT9 ? __builtin_nontemporal_load(&hi[(size_t)tl * n]) : hi[(size_t)tl * n];
 			uint32_t v[8];
 #pragma unroll
 			for (uint32_t u = 0; u < 8; u++)
-				v[u] = (u < qpt) ? lo[(size_t)(tl * qpt + u) * n] : 0u;
+				v[u] = (u < qpt) ? (K2_NT9 ? __builtin_nontemporal_load(&lo[(size_t)(tl * qpt + u) * n]) : lo[(size_t)(tl * qpt + u) * n]) : 0u;
 #pragma unroll
 			for (uint32_t u = 0; u < 8; u++) {
 				if (u < qpt) {			/* uniform */
