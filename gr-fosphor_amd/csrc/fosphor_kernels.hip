@@ -1327,8 +1327,12 @@ constexpr int kAuxNT = 2, kAuxSC1 = 16;		/* gfx94x / gfx950 cache-policy bits of
 #define K1H_IQ_MOD "sc1"
 #elif K1H_IQ_POL == 3
 #define K1H_IQ_MOD "sc0 sc1"
-#else
+#elif K1H_IQ_POL == 4
 #define K1H_IQ_MOD "sc0 sc1 nt"
+#elif K1H_IQ_POL == 5
+#define K1H_IQ_MOD "sc1 nt"
+#else
+#define K1H_IQ_MOD "sc0 nt"
 #endif
 #endif
 template <int AUX>
