@@ -107,11 +107,16 @@ def parse():
 # N > 1 without a launcher: start one as a child (no GPU call has been made in this process)
 # ---------------------------------------------------------------------------------------------------
 
-def scaling_record_guard(world, transport, exchange_ranks_per_rank, test_hook=False):
+def scaling_record_guard(world, transport, exchange_ranks_per_rank, test_hook=False, check=None):
     """A line measured on N > 1 ranks is a SCALING record (the driver computes efficiency from it): it must have exchanged through
     the native RCCL transport, and the library's communicator must span all N ranks on every rank (ncclCommCount).  Returns the
-    reason the record is invalid, or None.  test_hook: the ranks share one GPU over gloo on purpose (tests/test_gpu_dist.py):
-    the torch transport is then what is being tested."""
+    reason the record is invalid, or None.  check: config.exchange_check of the line (the reduced hit counts hold every spectrum of the
+    last frame once per column on every rank; the replicated state is bit-identical across ranks) -- wrong results fail the run
+    whatever the transport.  test_hook: the ranks share one GPU over gloo on purpose (tests/test_gpu_dist.py): the torch transport
+    is then what is being tested."""
+    if check is not None and world > 1 and not (check.get("every_spectrum_counted_once_on_every_rank")
+                                                and check.get("replicated_state_bit_identical_across_ranks")):
+        return "the exchange left wrong results (%s): not a scaling record" % check
     if world <= 1 or test_hook:
         return None
     if not str(transport).startswith("native RCCL"):
@@ -437,6 +442,27 @@ def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
     share1 = f.share_stats()
     xchg_ms, xchg_n = f.exchange_time()		# hipEvents around the ncclGroup on the count/merge stream (native transport)
     exchange_ranks = sf.exchange_ranks() if sf is not None else 1	# ncclCommCount of the library's communicator
+    # Frame mode, outside the timed region: what the exchange left on every rank.  No oracle here (the bench may not call it for the
+    # measured path) -- two properties the exchange must have whatever the data: the reduced hit counts of the last frame hold every
+    # spectrum of the frame exactly once per column (each rank's shard arrived, none twice), and the replicated state -- hit counts,
+    # histogram, spectrum -- is bit-identical on all ranks.
+    exchange_check = None
+    if sf is not None:
+        import hashlib
+        sf.gather_state()
+        if f.finish() < 0:
+            raise RuntimeError("device error")
+        hc = f.hitcount
+        per_column = F * spb * world
+        counts_ok = bool((hc.astype("int64").sum(0) == per_column).all())
+        dig = hashlib.sha256(hc.tobytes() + f.histogram.tobytes() + f.spectrum.tobytes()).digest()[:8]
+        mine = torch.tensor([int.from_bytes(dig, "little") >> 1, int(counts_ok)], dtype=torch.int64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(every, mine)
+        exchange_check = {"hit_counts_per_column": per_column,
+                          "every_spectrum_counted_once_on_every_rank": all(int(e[1].item()) == 1 for e in every),
+                          "replicated_state_bit_identical_across_ranks": all(int(e[0].item()) == int(every[0][0].item()) for e in every)}
 
     ms_all, n_all, iso, twin_ms = [0.0] * 3, [0] * 3, None, None
     if extra:
@@ -603,6 +629,7 @@ def measure(name, args, ctx, steps, warmup, light=False, batches_per_step=0):
                     "transport_agreement": transport,
                     "exchange_ranks": exchange_ranks,			# ncclCommCount(library communicator) on rank 0 (1 = no exchange)
                     "exchange_ranks_per_rank": xchg_ranks_all,
+                    "exchange_check": exchange_check,		# frame mode: properties of the reduced arrays, checked after the timed region
                     "exchange_ms_per_frame": (xchg_ms / xchg_n) if xchg_n else None,	# hipEvents around the ncclGroup, rank 0
                     "exchanges_timed": xchg_n,
                     "k1_busy_ms_per_launch_per_rank": {"min": min(k1_busy_ranks), "max": max(k1_busy_ranks), "all": k1_busy_ranks},
@@ -763,7 +790,8 @@ def main():
     if rank == 0 and out is not None:
         # no silent fallback in a scaling record: anything but the native exchange over all N ranks fails the run (exit code 3)
         guard = scaling_record_guard(world, out["config"].get("transport"), out["config"].get("exchange_ranks_per_rank", []),
-                                     test_hook=os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl") != "nccl")
+                                     test_hook=os.environ.get("FOSPHOR_BENCH_BACKEND", "nccl") != "nccl",
+                                     check=out["config"].get("exchange_check"))
         if guard:
             out["invalid"] = guard
             sys.stderr.write("bench.py: %s\n" % guard)

@@ -308,3 +308,9 @@ def test_bench_refuses_a_scaling_record_without_the_native_exchange():
     assert "not 8 on every rank" in g(8, native, [8] * 7)				# a rank did not report
     assert "not 2 on every rank" in g(2, native, [1, 1])
     assert g(2, "torch.distributed (gloo)", [2, 2], test_hook=True) is None		# tests/test_gpu_dist.py: meant
+    # ... and the line's own check of what the exchange left (every spectrum counted once per column on every rank, the replicated state
+    # bit-identical across ranks): wrong results fail the run whatever the transport
+    good = {"every_spectrum_counted_once_on_every_rank": True, "replicated_state_bit_identical_across_ranks": True}
+    assert g(8, native, [8] * 8, check=good) is None
+    assert "wrong results" in g(8, native, [8] * 8, check=dict(good, replicated_state_bit_identical_across_ranks=False))
+    assert "wrong results" in g(2, "torch.distributed (gloo)", [2, 2], test_hook=True, check=dict(good, every_spectrum_counted_once_on_every_rank=False))

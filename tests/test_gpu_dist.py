@@ -271,6 +271,9 @@ def test_bench_frame_mode_two_ranks_one_gpu(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
     assert j["config"]["mode"] == "frame" and "torch.distributed" in j["config"]["exchange"]
+    chk = j["config"]["exchange_check"]		# the line's own check of what the exchange left on the ranks
+    assert chk["every_spectrum_counted_once_on_every_rank"] and chk["replicated_state_bit_identical_across_ranks"], chk
+    assert chk["hit_counts_per_column"] == 2 * 256 * 1024
     # whole-job aggregate: both ranks' samples over the slowest rank's time
     assert abs(j["value"] * 1e6 * j["ms_per_step"] * 1e-3 - 2 * 256 * 1024 * 1024) < 1e3
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
