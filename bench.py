@@ -27,6 +27,10 @@ settled: the first milliseconds of a run are 10-30 % slower.
          every N (weak scaling, BASELINE configs[3] "C4").  FOSPHOR_AMD_FORCE_EXCHANGE=1 runs the
          collectives on a single rank.  `--mode frame --batches-per-step 1` is SURVEY 8e's "K = 1, honest
          worst case": one exchange per 1024-spectrum launch per GPU instead of one per display frame.
+         A multi-rank line is a scaling record only if the exchange was the native RCCL one over all N ranks
+         (config.transport, config.exchange_ranks_per_rank) and left right results (config.exchange_check, after the
+         timed region: every spectrum of the last frame counted once per column on every rank, the replicated state
+         bit-identical across ranks); otherwise the line is marked `invalid` and the run exits 3.
 
 Other BASELINE configurations: --config C3 (8192-pt FFT, 50 % overlap fused into the read, batch
 4096, 512 bins) and --config C5 (65536-pt FFT, fp16 IQ, 512 bins, the per-GPU share of a sharded
