@@ -46,7 +46,10 @@ static const int kMaxK1Streams = 4;	/* `stream` + up to three more FFT streams *
  * finds empty, no CU mask involved (hardware masks that remove CUs unevenly from the shader engines unbalance a grid of CU-sized
  * work-groups: tools/ubench/cu_mask_big.hip).  Measured at BASELINE C3: 333 -> 367-371 GSamples/s with 28 batches per call, 358
  * with 14, 345 with 7; 232 / 240 CUs leave the tail too little (it becomes the longer side), 216: 356 (DESIGN.md sections 4-5; DESIGN_HISTORY.md section 8). */
-static const int kK1wShareCus = 224;
+#ifndef K1W_SHARE_CUS
+#define K1W_SHARE_CUS 224		/* (A/B builds: 208 / 240 with 26 / 30 batches per call, profiles/r06_c3.md) */
+#endif
+static const int kK1wShareCus = K1W_SHARE_CUS;
 static const int kSubSamplesLog2 = 26;	/* default sub-launch: 64 Mi samples (64 reference batches of 1024 x 1024) */
 
 static const int kRiseMax = 8192;	/* largest batch served by the rise/decay table */
